@@ -1,0 +1,44 @@
+// Shared device/host helpers for libvoxvae (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/voxvae.h"
+
+#define VV_EXPORT extern "C" __attribute__((visibility("default")))
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+static inline bool vv_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int vv_log2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline bool vv_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t vv_dtype_size(int dt) { return dt == VV_BF16 ? 2 : 4; }
+static inline int vv_launch_status() { return hipGetLastError() == hipSuccess ? VV_OK : VV_ERR_LAUNCH; }
+
+// autoencoder3D.py:33-38: ELU(alpha 1) / ReLU / LeakyReLU(alpha 0.3, the Keras default)
+__device__ __forceinline__ float vv_apply_act(float v, int act) {
+    switch (act) {
+        case VV_ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case VV_ACT_RELU: return v > 0.f ? v : 0.f;
+        case VV_ACT_LRELU: return v > 0.f ? v : 0.3f * v;
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float vv_load_f32(const float *p, size_t i) { return p[i]; }
+__device__ __forceinline__ float vv_load_f32(const __bf16 *p, size_t i) { return static_cast<float>(p[i]); }
+__device__ __forceinline__ void vv_store(float *p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void vv_store(__bf16 *p, size_t i, float v) { p[i] = static_cast<__bf16>(v); }
+
+__device__ __forceinline__ float vv_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

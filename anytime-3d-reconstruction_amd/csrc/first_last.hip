@@ -1,0 +1,247 @@
+// The two HBM-bound ends of the path (gfx950):
+//   conv_first : Conv3D k4 s2 SAME with Cin = 1 on the float32 occupancy grid + BN + act   (autoencoder3D.py:26-39)
+//   final_bce  : Conv3DTranspose k4 s2 SAME -> 1 channel, sigmoid, weighted BCE and TP/FP/FN, fused
+//                (autoencoder3D.py:129-136; function.py:73-82, 100-115)
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_first.  4 lanes share one output voxel (16 output channels each); the 4x4x4 window of x is read through L1
+// (each x value is a wave-level broadcast to the 4 lanes and is re-read by the 8 neighbouring windows), the
+// [64 taps][Cout] weights live in LDS and are read as float4 broadcasts.  Output is the dominant stream:
+// Cout*sizeof(T) contiguous bytes per voxel.
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         T *__restrict__ y, int batch, int din_log2, int act) {
+    constexpr int G = COUT / 16;         // lanes per voxel
+    constexpr int VPB = 256 / G;         // voxels per pass
+    __shared__ __attribute__((aligned(16))) float wl[64 * COUT];
+    for (int i = threadIdx.x; i < 64 * COUT; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int li = din_log2, lo = li - 1, n = 1 << li, msk = (1 << lo) - 1;
+    const int g = threadIdx.x % G, vl = threadIdx.x / G;
+    const long nvox = (long)batch << (3 * lo);
+    float sc[16], sh[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        sc[c] = scale ? scale[g * 16 + c] : 1.f;
+        sh[c] = shift ? shift[g * 16 + c] : 0.f;
+    }
+    for (long v0 = (long)blockIdx.x * VPB; v0 < nvox; v0 += (long)gridDim.x * VPB) {
+        const long v = v0 + vl;
+        if (v >= nvox) continue;
+        const int ow = (int)(v & msk), oh = (int)((v >> lo) & msk), od = (int)((v >> (2 * lo)) & msk);
+        const long b = v >> (3 * lo);
+        const float *xb = x + (b << (3 * li));
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int td = 0; td < 4; ++td) {
+            const int id = 2 * od - 1 + td;
+#pragma unroll
+            for (int th = 0; th < 4; ++th) {
+                const int ih = 2 * oh - 1 + th;
+                const bool rowok = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n;
+#pragma unroll
+                for (int tw = 0; tw < 4; ++tw) {
+                    const int iw = 2 * ow - 1 + tw;
+                    const float xv = (rowok && (unsigned)iw < (unsigned)n) ? xb[(((long)id << li) + ih << li) + iw] : 0.f;
+                    const f32x4 *wp = reinterpret_cast<const f32x4 *>(wl + ((td * 4 + th) * 4 + tw) * COUT + g * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 wv = wp[q];
+                        acc[q * 4 + 0] = fmaf(xv, wv[0], acc[q * 4 + 0]);
+                        acc[q * 4 + 1] = fmaf(xv, wv[1], acc[q * 4 + 1]);
+                        acc[q * 4 + 2] = fmaf(xv, wv[2], acc[q * 4 + 2]);
+                        acc[q * 4 + 3] = fmaf(xv, wv[3], acc[q * 4 + 3]);
+                    }
+                }
+            }
+        }
+        T *yp = y + v * COUT + g * 16;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                o0[c] = static_cast<__bf16>(vv_apply_act(acc[c] * sc[c] + sh[c], act));
+                o1[c] = static_cast<__bf16>(vv_apply_act(acc[8 + c] * sc[8 + c] + sh[8 + c], act));
+            }
+            reinterpret_cast<bf16x8 *>(yp)[0] = o0;
+            reinterpret_cast<bf16x8 *>(yp)[1] = o1;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = vv_apply_act(acc[q * 4 + c] * sc[q * 4 + c] + sh[q * 4 + c], act);
+                reinterpret_cast<f32x4 *>(yp)[q] = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// final_bce.  One workgroup = a 4x4x4 block of input-grid cells (-> 8x8x8 logits) of one sample.  The 6x6x6 input
+// halo tile is staged in LDS as float32 rows (padded by 16 B against bank conflicts); wave w owns output parity
+// (pd,ph) = (w>>1, w&1) and each lane both pw parities of its cell, so the 16 weight vectors a wave needs are
+// wave-uniform and come through the scalar cache.  Loss terms are reduced by wave shuffles, then across the 4
+// waves in LDS, and written as one partial per workgroup; final_reduce sums a sample's partials in block order.
+constexpr int FB_CIN = 64;
+constexpr int FB_ROW = FB_CIN + 4;  // floats per staged voxel row (+16 B pad)
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_bce_kernel(const T *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ target, float *__restrict__ probs,
+                                                        float *__restrict__ logits, float *__restrict__ partials,
+                                                        int din_log2, float gamma, float epsilon) {
+    __shared__ __attribute__((aligned(16))) float tile[216 * FB_ROW];
+    __shared__ float red[4][4];
+    const int li = din_log2, n = 1 << li, nb = n >> 2;  // blocks per axis
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const int bw = blk % nb, bh = (blk / nb) % nb, bd = blk / (nb * nb);
+    const int m0d = bd * 4, m0h = bh * 4, m0w = bw * 4;
+    const T *xb = x + ((size_t)b << (3 * li)) * FB_CIN;
+
+    // stage the halo tile: 216 voxels x 64 channels, 16 B (= 4 f32 / 8 bf16 -> split) per lane per step
+    constexpr int EPL = 16 / sizeof(T);          // elements per 16-byte load
+    constexpr int LPV = FB_CIN / EPL;            // loads per voxel
+    for (int i = threadIdx.x; i < 216 * LPV; i += 256) {
+        const int vox = i / LPV, part = i % LPV;
+        const int zw = vox % 6, zh = (vox / 6) % 6, zd = vox / 36;
+        const int id = m0d - 1 + zd, ih = m0h - 1 + zh, iw = m0w - 1 + zw;
+        float vals[EPL];
+        if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n) {
+            const T *src = xb + ((((size_t)id << li) + ih << li) + iw) * FB_CIN + part * EPL;
+            const uint4 raw = *reinterpret_cast<const uint4 *>(src);
+            const T *rv = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) vals[e] = static_cast<float>(rv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) vals[e] = 0.f;
+        }
+        float *dst = tile + vox * FB_ROW + part * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<f32x4 *>(dst + e) = f32x4{vals[e], vals[e + 1], vals[e + 2], vals[e + 3]};
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pd = wv >> 1, ph = wv & 1;
+    const int mw = lane & 3, mh = (lane >> 2) & 3, md = lane >> 4;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int ad = 0; ad < 2; ++ad) {
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {
+            const int zd = md + pd - ad + 1, zh = mh + ph - ah + 1;
+            const int td = 1 - pd + 2 * ad, th = 1 - ph + 2 * ah;
+            const float *r0 = tile + ((zd * 6 + zh) * 6 + mw) * FB_ROW;  // zw = mw, mw+1, mw+2
+            const float *wt = w + (size_t)((td * 4 + th) * 4) * FB_CIN;  // [tw][ci], wave-uniform
+#pragma unroll 4
+            for (int c = 0; c < FB_CIN; c += 4) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(r0 + c);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(r0 + FB_ROW + c);
+                const f32x4 x2 = *reinterpret_cast<const f32x4 *>(r0 + 2 * FB_ROW + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // pw = 0: i = mw (tw 1), mw-1 (tw 3);  pw = 1: i = mw+1 (tw 0), mw (tw 2)
+                    acc0 = fmaf(x1[e], wt[1 * FB_CIN + c + e], acc0);
+                    acc0 = fmaf(x0[e], wt[3 * FB_CIN + c + e], acc0);
+                    acc1 = fmaf(x2[e], wt[0 * FB_CIN + c + e], acc1);
+                    acc1 = fmaf(x1[e], wt[2 * FB_CIN + c + e], acc1);
+                }
+            }
+        }
+    }
+    const int lo = li + 1;
+    const int od = 2 * (m0d + md) + pd, oh = 2 * (m0h + mh) + ph, ow = 2 * (m0w + mw);
+    const size_t o = ((((size_t)b << lo) + od << lo) + oh << lo) + ow;
+    const float2 y = *reinterpret_cast<const float2 *>(target + o);
+    const float l[2] = {acc0, acc1}, yy[2] = {y.x, y.y};
+    float p[2], bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    const float hi = 1.0f - epsilon;  // 0.99999988 in float32 (function.py:79)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        p[e] = 1.0f / (1.0f + expf(-l[e]));                         // tf.sigmoid, autoencoder3D.py:136
+        const float q = fminf(fmaxf(p[e], epsilon), hi);
+        bce -= gamma * yy[e] * logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * logf(1.0f - q);   // function.py:80
+        const float yh = p[e] >= 0.5f ? 1.f : 0.f;                  // function.py:110
+        tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
+    }
+    if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+    if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+    bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
+    if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        partials[((size_t)b * gridDim.x + blk) * 4 + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nblk) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < nblk; i += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(partials + ((size_t)b * nblk + i) * 4);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = vv_wave_sum(s[k]);
+    if (lane == 0) *reinterpret_cast<f32x4 *>(stats + (size_t)b * 4) = f32x4{s[0], s[1], s[2], s[3]};
+}
+
+}  // namespace
+
+VV_EXPORT int vv_conv3d_first_fwd(const float *x, const float *w_keras, const float *scale, const float *shift, void *y,
+                                  int batch, int side, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_keras || !y) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
+    if (batch <= 0 || side < 4 || !vv_is_pow2(side) || cout != 64) return VV_ERR_SHAPE;
+    if (!vv_aligned16(y)) return VV_ERR_ALIGN;
+    const int li = vv_log2(side);
+    const long nvox = (long)batch << (3 * (li - 1));
+    long blocks = (nvox + 255) / 256;  // 4 passes of 64 voxels per workgroup
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == VV_BF16)
+        hipLaunchKernelGGL((conv_first_kernel<__bf16, 64>), dim3((unsigned)blocks), dim3(256), 0, st, x, w_keras, scale, shift,
+                           reinterpret_cast<__bf16 *>(y), batch, li, act);
+    else
+        hipLaunchKernelGGL((conv_first_kernel<float, 64>), dim3((unsigned)blocks), dim3(256), 0, st, x, w_keras, scale, shift,
+                           reinterpret_cast<float *>(y), batch, li, act);
+    return vv_launch_status();
+}
+
+VV_EXPORT size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side) {
+    const size_t nb = side / 4;
+    return (size_t)batch * nb * nb * nb * 4 * sizeof(float);
+}
+
+VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *target, float *probs,
+                                       float *logits, float *stats, int batch, int side, int cin, float gamma,
+                                       float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !w_keras || !target || !stats) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
+    if (batch <= 0 || batch > 65535 || side < 4 || !vv_is_pow2(side) || cin != FB_CIN) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(target) || (probs && !vv_aligned16(probs)) || (logits && !vv_aligned16(logits)))
+        return VV_ERR_ALIGN;
+    if (!workspace || workspace_bytes < vv_convT3d_final_bce_workspace_bytes(batch, side) || !vv_aligned16(workspace))
+        return VV_ERR_WORKSPACE;
+    const int nb = side / 4, nblk = nb * nb * nb;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *partials = reinterpret_cast<float *>(workspace);
+    if (dtype == VV_BF16)
+        hipLaunchKernelGGL((final_bce_kernel<__bf16>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x),
+                           w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
+    else
+        hipLaunchKernelGGL((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                           w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
+    hipLaunchKernelGGL(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
+    return vv_launch_status();
+}

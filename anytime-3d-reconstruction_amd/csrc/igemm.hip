@@ -1,0 +1,384 @@
+// Implicit-GEMM convolution kernels on MFMA for gfx950 (CDNA4).
+//
+//   C[M,N] = gather(A)[M,K] * W[N,K]^T ;  y = act(C*scale[n] + shift[n])
+//
+// MODE_DENSE : A row m is K contiguous elements               (linearTransform, pooled E5, dense D1)
+// MODE_CONV  : Conv3D k4 s2 SAME, rows = output voxels, k = (tap 4x4x4, ci)      -- autoencoder3D.py:26-39
+// MODE_CONVT : Conv3DTranspose k4 s2 SAME as 8 output-parity sub-convolutions, rows = INPUT-grid cells,
+//              k = (tap 2x2x2, ci), blockIdx.z = parity                          -- autoencoder3D.py:41-54
+//
+// Channels-last makes every K chunk of one row a contiguous 128-byte segment (or zeros, for a tap in the
+// SAME padding), so both operands are staged as [rows][128 B] LDS images, XOR-swizzled per 16-byte slot so the
+// ds_read_b128 fragment reads are bank-conflict free, and consumed by v_mfma_f32_32x32x16_bf16 (bf16) or
+// v_mfma_f32_32x32x2_f32 (exact-f32 parity mode).  One 256-thread workgroup (4 waves, 2x2) owns a BM x BN tile;
+// global loads of chunk k+1 are in flight while chunk k is multiplied (register prefetch + LDS double buffer).
+// Split-K writes f32 slabs that igemm_splitk_epilogue sums in a fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_CONVT = 2 };
+
+struct IgemmArgs {
+    const void *A;
+    const void *W;
+    void *Out;
+    float *partial;  // split-K slabs [split][parity][M][N], or nullptr
+    const float *scale;
+    const float *shift;
+    int M, N, K;       // K per parity panel
+    int din_log2;      // log2(input side) for the conv modes
+    int cin;           // input channels for the conv modes
+    int cpt_log2;      // log2(chunks per tap) = log2(cin / BK)
+    int nchunks;       // K / BK
+    int chunks_per_split;
+    int act;
+    int out_bf16;      // output element type (1 bf16, 0 f32)
+};
+
+constexpr int ROWB = 128;  // bytes per staged row = one K chunk
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> struct Elt;
+template <> struct Elt<float> { static constexpr int BK = 32; };
+template <> struct Elt<__bf16> { static constexpr int BK = 64; };
+
+// Per-thread description of one A row it stages.
+struct RowCtx {
+    int off0;  // element offset of tap (0,0,0), channel 0 (may be "negative" for padded taps: never dereferenced)
+    int d0, h0, w0;
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ RowCtx make_row(const IgemmArgs &a, int m, int parity) {
+    RowCtx r;
+    r.ok = m < a.M;
+    if (MODE == MODE_DENSE) {
+        r.off0 = m * a.K;
+        r.d0 = r.h0 = r.w0 = 0;
+        return r;
+    }
+    const int li = a.din_log2, n = 1 << li;
+    int b;
+    if (MODE == MODE_CONV) {
+        const int lo = li - 1, msk = (1 << lo) - 1;
+        const int ow = m & msk, oh = (m >> lo) & msk, od = (m >> (2 * lo)) & msk;
+        b = m >> (3 * lo);
+        r.d0 = 2 * od - 1; r.h0 = 2 * oh - 1; r.w0 = 2 * ow - 1;  // SAME, k4 s2: pad_before = 1
+    } else {
+        const int msk = n - 1;
+        const int mw = m & msk, mh = (m >> li) & msk, md = (m >> (2 * li)) & msk;
+        b = m >> (3 * li);
+        r.d0 = md + ((parity >> 2) & 1); r.h0 = mh + ((parity >> 1) & 1); r.w0 = mw + (parity & 1);
+    }
+    r.off0 = (((b * n + r.d0) * n + r.h0) * n + r.w0) * a.cin;  // may be out of range for padded taps: never dereferenced
+    return r;
+}
+
+// element offset of (row, chunk kc) and its validity
+template <int MODE, int BK>
+__device__ __forceinline__ bool row_chunk(const IgemmArgs &a, const RowCtx &r, int kc, int chunk, int &off) {
+    if (MODE == MODE_DENSE) {  // K tail: 16-byte slots past K read as zero (K % slot == 0)
+        off = r.off0 + kc * BK;
+        return r.ok && kc * BK + chunk * (BK / 8) < a.K;
+    }
+    const int li = a.din_log2, n = 1 << li;
+    const int tap = kc >> a.cpt_log2, ci0 = (kc & ((1 << a.cpt_log2) - 1)) * BK;
+    if (MODE == MODE_CONV) {
+        const int td = tap >> 4, th = (tap >> 2) & 3, tw = tap & 3;
+        off = r.off0 + ((((td << li) + th) << li) + tw) * a.cin + ci0;
+        return r.ok && (unsigned)(r.d0 + td) < (unsigned)n && (unsigned)(r.h0 + th) < (unsigned)n &&
+               (unsigned)(r.w0 + tw) < (unsigned)n;
+    } else {
+        const int ad = tap >> 2, ah = (tap >> 1) & 1, aw = tap & 1;
+        off = r.off0 - ((((ad << li) + ah) << li) + aw) * a.cin + ci0;
+        return r.ok && (unsigned)(r.d0 - ad) < (unsigned)n && (unsigned)(r.h0 - ah) < (unsigned)n &&
+               (unsigned)(r.w0 - aw) < (unsigned)n;
+    }
+}
+
+// output element offset of row m (channel 0)
+template <int MODE>
+__device__ __forceinline__ size_t out_row(const IgemmArgs &a, int m, int parity) {
+    if (MODE != MODE_CONVT) return (size_t)m * a.N;
+    const int li = a.din_log2, msk = (1 << li) - 1, lo = li + 1;
+    const int mw = m & msk, mh = (m >> li) & msk, md = (m >> (2 * li)) & msk, b = m >> (3 * li);
+    const size_t od = 2 * md + ((parity >> 2) & 1), oh = 2 * mh + ((parity >> 1) & 1), ow = 2 * mw + (parity & 1);
+    return (((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow) * (size_t)a.N;
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_step(const uint4 &a, const uint4 &b, f32x16 &acc);
+template <>
+__device__ __forceinline__ void mma_step<__bf16>(const uint4 &a, const uint4 &b, f32x16 &acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a),
+                                                  *reinterpret_cast<const bf16x8 *>(&b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, f32x16 &acc) {
+    // lane (r,h) holds k = 4h..4h+3 of this 8-deep step; MFMA q pairs k = q (h=0) with k = 4+q (h=1): a fixed
+    // permutation of k applied to both operands.
+    const float *af = reinterpret_cast<const float *>(&a);
+    const float *bf = reinterpret_cast<const float *>(&b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc, 0, 0, 0);
+}
+
+template <typename T, int MODE, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int BK = Elt<T>::BK;
+    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 tiles per wave (waves laid out 2 x 2)
+    constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *As = smem;                       // [2][BM][128]
+    char *Bs = smem + 2 * BM * ROWB;       // [2][BN][128]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int split = blockIdx.y, parity = blockIdx.z;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kc_begin = split * a.chunks_per_split;
+    const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
+
+    const int chunk = tid & 7, r0 = tid >> 3;
+    const char *Ab = reinterpret_cast<const char *>(a.A);
+    const char *Wb = reinterpret_cast<const char *>(a.W) + (size_t)parity * a.N * a.K * sizeof(T);
+
+    RowCtx rows[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) rows[i] = make_row<MODE>(a, m0 + r0 + 32 * i, parity);
+    size_t wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wrow[i] = (size_t)(n0 + r0 + 32 * i) * a.K * sizeof(T) + chunk * 16;
+
+    uint4 ra[RA], rb[RB];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int off;
+            const bool v = row_chunk<MODE, BK>(a, rows[i], kc, chunk, off);
+            ra[i] = v ? *reinterpret_cast<const uint4 *>(Ab + (long)off * (long)sizeof(T) + chunk * 16) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = (n0 + r0 + 32 * i < a.N && (MODE != MODE_DENSE || kc * BK + chunk * (BK / 8) < a.K))
+                        ? *reinterpret_cast<const uint4 *>(Wb + wrow[i] + (size_t)kc * ROWB) : make_uint4(0, 0, 0, 0);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4 *>(As + buf * BM * ROWB + lds_off(r0 + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(Bs + buf * BN * ROWB + lds_off(r0 + 32 * i, chunk)) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    if (kc_begin < kc_end) {
+        gload(kc_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const bool more = kc + 1 < kc_end;
+        if (more) gload(kc + 1);
+        const char *Ac = As + buf * BM * ROWB, *Bc = Bs + buf * BN * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const uint4 *>(Ac + lds_off(wm * (BM / 2) + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const uint4 *>(Bc + lds_off(wn * (BN / 2) + j * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: lane owns column n, registers walk rows (32x32 C/D map: row = (q&3) + 8*(q>>2) + 4*h)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+        if (n >= a.N) continue;
+        float sc = 1.f, sh = 0.f;
+        if (!a.partial) {
+            if (a.scale) sc = a.scale[n];
+            if (a.shift) sh = a.shift[n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                if (m >= a.M) continue;
+                if (a.partial) {
+                    a.partial[((size_t)(split * gridDim.z + parity) * a.M + m) * a.N + n] = acc[i][j][q];
+                } else {
+                    const float v = vv_apply_act(acc[i][j][q] * sc + sh, a.act);
+                    const size_t o = out_row<MODE>(a, m, parity) + n;
+                    if (a.out_bf16) reinterpret_cast<__bf16 *>(a.Out)[o] = static_cast<__bf16>(v);
+                    else reinterpret_cast<float *>(a.Out)[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// Sums the split-K slabs in split order, applies the folded BN + activation, scatters to the output.
+template <int MODE>
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int nsplit, int nparity) {
+    const int n4 = a.N >> 2;
+    const size_t total = (size_t)nparity * a.M * n4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % n4);
+        const size_t pm = i / n4;
+        const int m = (int)(pm % a.M), parity = (int)(pm / a.M);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < nsplit; ++sp)
+            s += *reinterpret_cast<const f32x4 *>(a.partial + (((size_t)(sp * nparity + parity) * a.M + m) * a.N + c4 * 4));
+        const size_t o = out_row<MODE>(a, m, parity) + c4 * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = c4 * 4 + q;
+            const float v = vv_apply_act(s[q] * (a.scale ? a.scale[n] : 1.f) + (a.shift ? a.shift[n] : 0.f), a.act);
+            if (a.out_bf16) reinterpret_cast<__bf16 *>(a.Out)[o + q] = static_cast<__bf16>(v);
+            else reinterpret_cast<float *>(a.Out)[o + q] = v;
+        }
+    }
+}
+
+struct Plan {
+    int bm, bn, split, cps, nparity;
+    size_t ws_bytes;
+};
+
+// Tile / split-K choice: fill >= 2 workgroups per CU (256 CUs) when the tile grid alone cannot.
+Plan make_plan(int mode, int M, int N, int K, int dtype) {
+    Plan p;
+    p.nparity = mode == MODE_CONVT ? 8 : 1;
+    p.bm = 128;
+    p.bn = (N % 128 == 0) ? 128 : 64;  // N tail (N % 64 != 0): weight rows past N read as zero, stores masked
+    const int bk = dtype == VV_BF16 ? 64 : 32;
+    const int nchunks = (K + bk - 1) / bk;
+    const long tiles = (long)((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn) * p.nparity;
+    int split = 1;
+    while (tiles * split < 512 && split * 2 <= nchunks / 8 && split < 64) split *= 2;
+    p.cps = (nchunks + split - 1) / split;
+    p.split = (nchunks + p.cps - 1) / p.cps;
+    p.ws_bytes = p.split > 1 ? (size_t)p.split * p.nparity * M * N * sizeof(float) : 0;
+    return p;
+}
+
+template <typename T, int MODE>
+int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
+    const int tiles = ((a.M + p.bm - 1) / p.bm) * ((a.N + p.bn - 1) / p.bn);
+    dim3 grid(tiles, p.split, p.nparity);
+    const size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB;
+    static const bool attr_set = [] {  // 64 KiB of dynamic LDS for the 128x128 tile
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * ROWB);
+        return true;
+    }();
+    (void)attr_set;
+    if (p.bn == 128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, 128>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, 64>), grid, dim3(256), lds, st, a);
+    if (p.split > 1) {
+        const size_t total = (size_t)p.nparity * a.M * (a.N / 4);
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL((igemm_splitk_epilogue<MODE>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity);
+    }
+    return vv_launch_status();
+}
+
+int run_igemm(int mode, const void *x, const void *w, const float *scale, const float *shift, void *y, int M, int N,
+              int K, int din, int cin, int act, int dtype, int out_dtype, void *ws, size_t ws_bytes, void *stream) {
+    if (!x || !w || !y) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
+    if (out_dtype != VV_F32 && out_dtype != VV_BF16) return VV_ERR_DTYPE;
+    const int bk = dtype == VV_BF16 ? 64 : 32;
+    if (M <= 0 || N <= 0 || K <= 0 || N % 4) return VV_ERR_SHAPE;
+    if (mode == MODE_DENSE ? (K % (bk / 8)) != 0 : (K % bk) != 0) return VV_ERR_SHAPE;
+    if (mode != MODE_DENSE && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w) || !vv_aligned16(y)) return VV_ERR_ALIGN;
+    const Plan p = make_plan(mode, M, N, K, dtype);
+    if (p.split > 1 && (!ws || ws_bytes < p.ws_bytes || !vv_aligned16(ws))) return VV_ERR_WORKSPACE;
+    IgemmArgs a;
+    a.A = x; a.W = w; a.Out = y;
+    a.partial = p.split > 1 ? reinterpret_cast<float *>(ws) : nullptr;
+    a.scale = scale; a.shift = shift;
+    a.M = M; a.N = N; a.K = K;
+    a.din_log2 = mode == MODE_DENSE ? 0 : vv_log2(din);
+    a.cin = cin;
+    a.cpt_log2 = mode == MODE_DENSE ? 0 : vv_log2(cin / bk);
+    a.nchunks = (K + bk - 1) / bk;
+    a.chunks_per_split = p.cps;
+    a.act = act;
+    a.out_bf16 = out_dtype == VV_BF16;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == VV_BF16) {
+        if (mode == MODE_DENSE) return launch_t<__bf16, MODE_DENSE>(a, p, st);
+        if (mode == MODE_CONV) return launch_t<__bf16, MODE_CONV>(a, p, st);
+        return launch_t<__bf16, MODE_CONVT>(a, p, st);
+    }
+    if (mode == MODE_DENSE) return launch_t<float, MODE_DENSE>(a, p, st);
+    if (mode == MODE_CONV) return launch_t<float, MODE_CONV>(a, p, st);
+    return launch_t<float, MODE_CONVT>(a, p, st);
+}
+
+}  // namespace
+
+VV_EXPORT size_t vv_conv3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype) {
+    const int o = side / 2;
+    return make_plan(MODE_CONV, batch * o * o * o, cout, 64 * cin, dtype).ws_bytes;
+}
+
+VV_EXPORT int vv_conv3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                 int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (batch <= 0 || side < 2 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
+    const int o = side / 2;
+    if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
+    return run_igemm(MODE_CONV, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64 * cin, side, cin, act, dtype,
+                     dtype, workspace, workspace_bytes, stream);
+}
+
+VV_EXPORT size_t vv_convT3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype) {
+    return make_plan(MODE_CONVT, batch * side * side * side, cout, 8 * cin, dtype).ws_bytes;
+}
+
+VV_EXPORT int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                  int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    if (batch <= 0 || side < 1 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
+    if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
+    return run_igemm(MODE_CONVT, x, w_packed, scale, shift, y, batch * side * side * side, cout, 8 * cin, side, cin, act,
+                     dtype, dtype, workspace, workspace_bytes, stream);
+}
+
+VV_EXPORT size_t vv_dense_workspace_bytes(int m, int n, int k, int dtype) { return make_plan(MODE_DENSE, m, n, k, dtype).ws_bytes; }
+
+VV_EXPORT int vv_dense_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y, int m,
+                           int n, int k, int act, int dtype, int out_dtype, void *workspace, size_t workspace_bytes,
+                           void *stream) {
+    if ((long)m * k >= (1L << 31)) return VV_ERR_SHAPE;
+    return run_igemm(MODE_DENSE, x, w_packed, scale, shift, y, m, n, k, 0, 0, act, dtype, out_dtype, workspace,
+                     workspace_bytes, stream);
+}

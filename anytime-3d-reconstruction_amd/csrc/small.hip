@@ -1,0 +1,245 @@
+// Weight packing, BatchNorm folding, the fused latent op and the metric finalisation: small, HBM/latency-bound
+// kernels around the MFMA convolutions.  gfx950 only.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_conv_k4_kernel(const float *__restrict__ w, T *__restrict__ out, int cin, int cout) {
+    // out[co][t*cin + ci] = w[t][ci][co]
+    const size_t total = (size_t)64 * cin * cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int K = 64 * cin;
+        const int co = (int)(i / K), k = (int)(i % K);
+        const int t = k / cin, ci = k % cin;
+        vv_store(out, i, w[((size_t)t * cin + ci) * cout + co]);
+    }
+}
+
+template <typename T>
+__global__ void pack_convT_k4s2_kernel(const float *__restrict__ w, T *__restrict__ out, int cin, int cout) {
+    // out[p][co][a*cin + ci] = w[t(p,a)][co][ci],  t = 1 - p + 2a per axis
+    const int K = 8 * cin;
+    const size_t total = (size_t)8 * cout * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const size_t pc = i / K;
+        const int co = (int)(pc % cout), p = (int)(pc / cout);
+        const int a = k / cin, ci = k % cin;
+        const int td = 1 - ((p >> 2) & 1) + 2 * ((a >> 2) & 1);
+        const int th = 1 - ((p >> 1) & 1) + 2 * ((a >> 1) & 1);
+        const int tw = 1 - (p & 1) + 2 * (a & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        vv_store(out, i, w[((size_t)t * cout + co) * cin + ci]);
+    }
+}
+
+template <typename T>
+__global__ void pack_conv_k4s1_meanpool_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
+    // out[co][i*cin + ci] = (1/S^3) * sum_{o : 0 <= i - o + 1 <= 3 per axis} w[i - o + 1][ci][co]
+    const int S3 = side * side * side, K = S3 * cin;
+    const size_t total = (size_t)cout * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx / K), k = (int)(idx % K);
+        const int i = k / cin, ci = k % cin;
+        const int iw = i % side, ih = (i / side) % side, id = i / (side * side);
+        float s = 0.f;
+        for (int od = 0; od < side; ++od) {
+            const int td = id - od + 1;
+            if (td < 0 || td > 3) continue;
+            for (int oh = 0; oh < side; ++oh) {
+                const int th = ih - oh + 1;
+                if (th < 0 || th > 3) continue;
+                for (int ow = 0; ow < side; ++ow) {
+                    const int tw = iw - ow + 1;
+                    if (tw < 0 || tw > 3) continue;
+                    s += w[((size_t)((td * 4 + th) * 4 + tw) * cin + ci) * cout + co];
+                }
+            }
+        }
+        vv_store(out, idx, s / (float)S3);
+    }
+}
+
+template <typename T>
+__global__ void pack_convT_k4s1_dense_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
+    // out[(o,co)][(j,ci)] = w[o - j + 1][co][ci] (0 when a tap index leaves 0..3)
+    const int S3 = side * side * side, K = S3 * cin;
+    const size_t total = (size_t)S3 * cout * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K);
+        const size_t n = idx / K;
+        const int co = (int)(n % cout), o = (int)(n / cout);
+        const int j = k / cin, ci = k % cin;
+        const int td = o / (side * side) - j / (side * side) + 1;
+        const int th = (o / side) % side - (j / side) % side + 1;
+        const int tw = o % side - j % side + 1;
+        float v = 0.f;
+        if ((unsigned)td < 4u && (unsigned)th < 4u && (unsigned)tw < 4u)
+            v = w[((size_t)((td * 4 + th) * 4 + tw) * cout + co) * cin + ci];
+        vv_store(out, idx, v);
+    }
+}
+
+template <typename T>
+__global__ void pack_dense_kernel(const float *__restrict__ w, T *__restrict__ out, int in, int outn) {
+    const size_t total = (size_t)in * outn;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx / in), i = (int)(idx % in);
+        vv_store(out, idx, w[(size_t)i * outn + o]);
+    }
+}
+
+__global__ void fold_bn_kernel(const float *gamma, const float *beta, const float *mean, const float *var,
+                               const float *bias, float eps, float *scale, float *shift, int c, int repeat) {
+    const int total = c * repeat;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = i % c;
+        const float sc = gamma[ch] / sqrtf(var[ch] + eps);
+        scale[i] = sc;
+        shift[i] = beta[ch] + ((bias ? bias[ch] : 0.f) - mean[ch]) * sc;
+    }
+}
+
+// One wave per sample row: slice | clip | sqrt(exp(lv))*eps | dropout | KL row sum by wave shuffles.
+template <typename TA>
+__global__ __launch_bounds__(256) void reparam_kl_kernel(const float *__restrict__ enc_out, const float *__restrict__ eps,
+                                                         const float *__restrict__ drop_mask, float drop_scale,
+                                                         float *__restrict__ z, TA *__restrict__ z_act,
+                                                         float *__restrict__ kl, float *__restrict__ mean_out,
+                                                         float *__restrict__ logvar_out, int batch, int L) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float mu = enc_out[(size_t)b * 2 * L + j];
+        float lv = enc_out[(size_t)b * 2 * L + L + j];
+        lv = fminf(fmaxf(lv, -10.f), 10.f);                    // nolbo.py:1420
+        const float e = expf(lv);
+        float zz = mu + sqrtf(e) * eps[(size_t)b * L + j];     // function.py:37
+        if (drop_mask) zz = zz * drop_mask[(size_t)b * L + j] * drop_scale;  // nolbo.py:1423-1425
+        z[(size_t)b * L + j] = zz;
+        if (z_act) vv_store(z_act, (size_t)b * L + j, zz);
+        if (mean_out) mean_out[(size_t)b * L + j] = mu;
+        if (logvar_out) logvar_out[(size_t)b * L + j] = lv;
+        s += 0.5f * (0.f - lv) + (e + mu * mu) / 2.0f - 0.5f;  // function.py:96 with target N(0, I)
+    }
+    s = vv_wave_sum(s);
+    if (kl && lane == 0) kl[b] = s;
+}
+
+// nolbo.py:1498-1501 batch means, summed in sample order by one wave (deterministic).
+__global__ __launch_bounds__(64) void shape_metrics_kernel(const float *__restrict__ stats, float *__restrict__ out4, int batch) {
+    const int lane = threadIdx.x;
+    float bce = 0.f, pr = 0.f, rc = 0.f, iou = 0.f;
+    for (int b = lane; b < batch; b += 64) {
+        const float l = stats[b * 4 + 0], tp = stats[b * 4 + 1], fp = stats[b * 4 + 2], fn = stats[b * 4 + 3];
+        bce += l;
+        pr += tp / (tp + fp + 1e-10f);
+        rc += tp / (tp + fn + 1e-10f);
+        iou += tp / fmaxf(tp + fp + fn, 1.f);
+    }
+    bce = vv_wave_sum(bce); pr = vv_wave_sum(pr); rc = vv_wave_sum(rc); iou = vv_wave_sum(iou);
+    if (lane == 0) {
+        out4[0] = bce / batch; out4[1] = pr / batch; out4[2] = rc / batch; out4[3] = iou / batch;
+    }
+}
+
+inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+#define VV_PACK_DISPATCH(KERNEL, TOTAL, ...)                                                                   \
+    do {                                                                                                       \
+        if (!w_keras || !packed) return VV_ERR_NULL;                                                           \
+        if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;                                          \
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                \
+        if (dtype == VV_BF16)                                                                                  \
+            hipLaunchKernelGGL((KERNEL<__bf16>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,             \
+                               reinterpret_cast<__bf16 *>(packed), __VA_ARGS__);                               \
+        else                                                                                                   \
+            hipLaunchKernelGGL((KERNEL<float>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,              \
+                               reinterpret_cast<float *>(packed), __VA_ARGS__);                                \
+        return vv_launch_status();                                                                             \
+    } while (0)
+
+VV_EXPORT int vv_abi_version(void) { return 1; }
+
+VV_EXPORT const char *vv_status_string(int s) {
+    switch (s) {
+        case VV_OK: return "ok";
+        case VV_ERR_NULL: return "required pointer is NULL";
+        case VV_ERR_SHAPE: return "unsupported or inconsistent shape";
+        case VV_ERR_DTYPE: return "unsupported dtype";
+        case VV_ERR_ALIGN: return "pointer not 16-byte aligned";
+        case VV_ERR_WORKSPACE: return "workspace missing or too small";
+        case VV_ERR_LAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}
+
+VV_EXPORT int vv_pack_conv_k4(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream) {
+    if (cin <= 0 || cout <= 0) return VV_ERR_SHAPE;
+    VV_PACK_DISPATCH(pack_conv_k4_kernel, (size_t)64 * cin * cout, cin, cout);
+}
+
+VV_EXPORT int vv_pack_convT_k4s2(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream) {
+    if (cin <= 0 || cout <= 0) return VV_ERR_SHAPE;
+    VV_PACK_DISPATCH(pack_convT_k4s2_kernel, (size_t)64 * cin * cout, cin, cout);
+}
+
+VV_EXPORT int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int side, int cin, int cout, int dtype,
+                                         void *stream) {
+    if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
+    VV_PACK_DISPATCH(pack_conv_k4s1_meanpool_kernel, (size_t)side * side * side * cin * cout, side, cin, cout);
+}
+
+VV_EXPORT int vv_pack_convT_k4s1_dense(const float *w_keras, void *packed, int side, int cin, int cout, int dtype,
+                                       void *stream) {
+    if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
+    const size_t s3 = (size_t)side * side * side;
+    VV_PACK_DISPATCH(pack_convT_k4s1_dense_kernel, s3 * cout * s3 * cin, side, cin, cout);
+}
+
+VV_EXPORT int vv_pack_dense(const float *w_keras, void *packed, int in, int out, int dtype, void *stream) {
+    if (in <= 0 || out <= 0) return VV_ERR_SHAPE;
+    VV_PACK_DISPATCH(pack_dense_kernel, (size_t)in * out, in, out);
+}
+
+VV_EXPORT int vv_fold_bn(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias,
+                         float eps, float *scale, float *shift, int channels, int repeat, void *stream) {
+    if (!gamma || !beta || !mean || !var || !scale || !shift) return VV_ERR_NULL;
+    if (channels <= 0 || repeat <= 0) return VV_ERR_SHAPE;
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(grid_for((size_t)channels * repeat)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gamma, beta, mean, var, bias, eps, scale, shift, channels,
+                       repeat);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_reparam_kl_fwd(const float *enc_out, const float *eps, const float *drop_mask, float drop_scale, float *z,
+                                void *z_act, int act_dtype, float *kl, float *mean, float *logvar, int batch, int latent,
+                                void *stream) {
+    if (!enc_out || !eps || !z) return VV_ERR_NULL;
+    if (batch <= 0 || latent <= 0) return VV_ERR_SHAPE;
+    if (z_act && act_dtype != VV_F32 && act_dtype != VV_BF16) return VV_ERR_DTYPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((batch + 3) / 4), block(256);
+    if (z_act && act_dtype == VV_BF16)
+        hipLaunchKernelGGL((reparam_kl_kernel<__bf16>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
+                           reinterpret_cast<__bf16 *>(z_act), kl, mean, logvar, batch, latent);
+    else
+        hipLaunchKernelGGL((reparam_kl_kernel<float>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
+                           reinterpret_cast<float *>(z_act), kl, mean, logvar, batch, latent);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_shape_metrics(const float *stats, float *out4, int batch, void *stream) {
+    if (!stats || !out4) return VV_ERR_NULL;
+    if (batch <= 0) return VV_ERR_SHAPE;
+    hipLaunchKernelGGL(shape_metrics_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), stats, out4, batch);
+    return vv_launch_status();
+}

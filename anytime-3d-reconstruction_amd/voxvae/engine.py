@@ -1,0 +1,278 @@
+"""Device-side engines for the two sub-models of the hot path.
+
+`EncoderEngine` / `DecoderEngine` own the float32 master weights (Keras layouts, torch CUDA
+tensors), the packed MFMA panels derived from them and the layer chain, and drive the C ABI
+(voxvae.lib).  torch is used for device memory and the current HIP stream only; every
+arithmetic step is a libvoxvae kernel.  Reference: src/net_core/autoencoder3D.py:72-139.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+BN_EPS = 1e-3  # Keras BatchNormalization default (autoencoder3D.py:31)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _tdtype(dt):
+    return torch.bfloat16 if dt == L.VV_BF16 else torch.float32
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise L.VoxVaeError('no HIP device visible: the voxel VAE path runs on MI355X only (no CPU fallback)')
+
+
+class _Workspace:
+    """Grow-only scratch buffer shared by the layers of one engine (split-K slabs, loss partials)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = max(int(nbytes), 16)
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class _EngineBase:
+    def __init__(self, structure, dtype, device):
+        _require_gpu()
+        L.load()
+        self.structure = structure
+        self.dt = L.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self.tdt = _tdtype(self.dt)
+        self.device = torch.device(device)
+        self.params = {}          # name -> float32 CUDA tensor, Keras layout (the trainable/master copy)
+        self.packed = {}
+        self.ws = _Workspace(self.device)
+        self._dirty = True
+        self.act = L.ACT[structure['activation']]
+
+    # ---- weights
+    def set_params(self, params):
+        for k, v in params.items():
+            t = torch.as_tensor(np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v, dtype=torch.float32)
+            if k in self.params and tuple(self.params[k].shape) != tuple(t.shape):
+                raise ValueError('%s: shape %s != %s' % (k, tuple(t.shape), tuple(self.params[k].shape)))
+            self.params[k] = t.to(self.device).contiguous()
+        self._dirty = True
+
+    def get_params(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.params.items()}
+
+    def _fold(self, prefix, channels, repeat=1, bias=None):
+        p = self.params
+        scale = torch.empty(channels * repeat, dtype=torch.float32, device=self.device)
+        shift = torch.empty_like(scale)
+        L.call('vv_fold_bn', L.ptr(p[prefix + '/gamma']), L.ptr(p[prefix + '/beta']), L.ptr(p[prefix + '/moving_mean']),
+               L.ptr(p[prefix + '/moving_variance']), L.ptr(bias), BN_EPS, L.ptr(scale), L.ptr(shift), channels, repeat,
+               _stream())
+        return scale, shift
+
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+
+    def ensure_packed(self):
+        if self._dirty:
+            self._pack()
+            self._dirty = False
+
+
+def _check_cubic_pow2(shape):
+    d = int(shape[0])
+    if len(shape) != 4 or shape[1] != d or shape[2] != d or d & (d - 1):
+        raise ValueError('voxel grid must be cubic with a power-of-two side, got %s' % (shape,))
+    return d
+
+
+class EncoderEngine(_EngineBase):
+    """encoder3D (autoencoder3D.py:72-102): [B,D,D,D,1] -> [B,E] float32."""
+
+    def __init__(self, structure, dtype='bf16', device='cuda:0'):
+        super().__init__(structure, dtype, device)
+        s = structure
+        self.D = _check_cubic_pow2(s['input_shape'])
+        self.filters = [int(c) for c in s['filter_num_list']]
+        n = len(self.filters)
+        if s['input_shape'][-1] != 1:
+            raise NotImplementedError('encoder input must have 1 channel (occupancy grid)')
+        if any(int(k) != 4 for k in s['filter_size_list']) or [int(v) for v in s['strides_list']] != [2] * (n - 1) + [1]:
+            raise NotImplementedError('encoder3D kernels cover filter size 4 with strides [2]*(n-1)+[1] '
+                                      '(every config of the reference)')
+        if s['final_pool'] != 'average':
+            raise NotImplementedError("final_pool=%r: only 'average' (used by every reference config)" % s['final_pool'])
+        if s['final_activation'] not in (None, 'None', 'linear'):
+            raise NotImplementedError('encoder final_activation %r' % s['final_activation'])
+        if self.D >> (n - 1) < 1:
+            raise ValueError('grid too small for %d stride-2 layers' % (n - 1))
+        self.S = self.D >> (n - 1)      # side of the last feature map
+        self.E = self.filters[-1]
+
+    def param_shapes(self):
+        shp, cin = {}, 1
+        for i, c in enumerate(self.filters):
+            shp['conv%d/kernel' % i] = (4, 4, 4, cin, c)
+            if i < len(self.filters) - 1:
+                for nme in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+                    shp['bn%d/%s' % (i, nme)] = (c,)
+            cin = c
+        return shp
+
+    def _pack(self):
+        p, f, st = self.params, self.filters, _stream()
+        self.packed = {'scale0': None}
+        self.packed['scale0'], self.packed['shift0'] = self._fold('bn0', f[0])
+        for i in range(1, len(f) - 1):
+            w = self._empty(f[i], 64 * f[i - 1])
+            L.call('vv_pack_conv_k4', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), f[i - 1], f[i], self.dt, st)
+            self.packed['w%d' % i] = w
+            self.packed['scale%d' % i], self.packed['shift%d' % i] = self._fold('bn%d' % i, f[i])
+        i = len(f) - 1
+        w = self._empty(f[i], self.S ** 3 * f[i - 1])
+        L.call('vv_pack_conv_k4s1_meanpool', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), self.S, f[i - 1], f[i], self.dt, st)
+        self.packed['w%d' % i] = w
+
+    def forward(self, x):
+        """x: float32 CUDA tensor [B,D,D,D,1] (contiguous) -> enc_out float32 [B,E]."""
+        self.ensure_packed()
+        B, D, f, pk, st = x.shape[0], self.D, self.filters, self.packed, _stream()
+        if tuple(x.shape[1:]) != (D, D, D, 1) or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError('encoder input must be contiguous float32 [B,%d,%d,%d,1], got %s %s' % (D, D, D, tuple(x.shape), x.dtype))
+        side = D // 2
+        h = self._empty(B, side, side, side, f[0])
+        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(self.params['conv0/kernel']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
+               L.ptr(h), B, D, f[0], self.act, self.dt, st)
+        for i in range(1, len(f) - 1):
+            nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt)
+            ws = self.ws.get(nb)
+            o = self._empty(B, side // 2, side // 2, side // 2, f[i])
+            L.call('vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                   L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+            h, side = o, side // 2
+        i = len(f) - 1
+        K = side ** 3 * f[i - 1]
+        nb = L.load().vv_dense_workspace_bytes(B, f[i], K, self.dt)
+        ws = self.ws.get(nb)
+        out = self._empty(B, f[i], dtype=torch.float32)
+        L.call('vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), None, None, L.ptr(out), B, f[i], K, 0, self.dt, L.VV_F32,
+               L.ptr(ws), ws.numel(), st)
+        return out
+
+
+class DecoderEngine(_EngineBase):
+    """decoder3D (autoencoder3D.py:104-139): z [B,L] -> logits/probabilities [B,D,D,D,1] float32,
+    with the BCE / TP / FP / FN reductions of function.py:73-115 fused into the last layer."""
+
+    def __init__(self, structure, dtype='bf16', device='cuda:0'):
+        super().__init__(structure, dtype, device)
+        s = structure
+        self.D = _check_cubic_pow2(s['output_shape'])
+        self.filters = [int(c) for c in s['filter_num_list']]
+        n = len(self.filters)
+        if any(int(k) != 4 for k in s['filter_size_list']) or [int(v) for v in s['strides_list']] != [1] + [2] * (n - 1):
+            raise NotImplementedError('decoder3D kernels cover filter size 4 with strides [1]+[2]*(n-1) '
+                                      '(every config of the reference)')
+        if self.filters[-1] != 1 or s['output_shape'][-1] != 1:
+            raise NotImplementedError('decoder must end in 1 channel')
+        self.L = int(s['input_dim'])
+        self.S = self.D >> (n - 1)                      # autoencoder3D.py:115
+        self.ch = max(self.filters[0] // 64, 8)         # autoencoder3D.py:116-118
+        self.final_sigmoid = s['final_activation'] == 'sigmoid'
+        if not self.final_sigmoid and s['final_activation'] not in (None, 'None', 'linear'):
+            raise NotImplementedError('decoder final_activation %r' % s['final_activation'])
+
+    def param_shapes(self):
+        lin = self.S ** 3 * self.ch
+        shp = {'dense/kernel': (self.L, lin), 'dense/bias': (lin,)}
+        for nme in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            shp['bn_dense/' + nme] = (lin,)
+        cin = self.ch
+        for i, c in enumerate(self.filters):
+            shp['convT%d/kernel' % i] = (4, 4, 4, c, cin)
+            if i < len(self.filters) - 1:
+                for nme in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+                    shp['bnT%d/%s' % (i, nme)] = (c,)
+            cin = c
+        return shp
+
+    def _pack(self):
+        p, f, st, S3 = self.params, self.filters, _stream(), self.S ** 3
+        lin = S3 * self.ch
+        pk = self.packed = {}
+        pk['wd'] = self._empty(lin, self.L)
+        L.call('vv_pack_dense', L.ptr(p['dense/kernel']), L.ptr(pk['wd']), self.L, lin, self.dt, st)
+        pk['scaled'], pk['shiftd'] = self._fold('bn_dense', lin, 1, p['dense/bias'])
+        pk['w0'] = self._empty(S3 * f[0], lin)
+        L.call('vv_pack_convT_k4s1_dense', L.ptr(p['convT0/kernel']), L.ptr(pk['w0']), self.S, self.ch, f[0], self.dt, st)
+        pk['scale0'], pk['shift0'] = self._fold('bnT0', f[0], S3)
+        for i in range(1, len(f) - 1):
+            pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1])
+            L.call('vv_pack_convT_k4s2', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['w%d' % i]), f[i - 1], f[i], self.dt, st)
+            pk['scale%d' % i], pk['shift%d' % i] = self._fold('bnT%d' % i, f[i])
+
+    def forward(self, z_act, target=None, want_logits=False, gamma=0.6, epsilon=1e-7):
+        """z_act: [B,L] in the activation dtype.  target: float32 [B,D,D,D,1] or None.
+        Returns (out, logits, stats): out = probabilities (final_activation 'sigmoid') or logits;
+        stats float32 [B,4] = per-sample (bce, TP, FP, FN) against target (zeros if None)."""
+        self.ensure_packed()
+        B, D, f, pk, st, S = z_act.shape[0], self.D, self.filters, self.packed, _stream(), self.S
+        if z_act.dtype != self.tdt or tuple(z_act.shape) != (B, self.L) or not z_act.is_contiguous():
+            raise ValueError('decoder input must be contiguous %s [B,%d]' % (self.tdt, self.L))
+        lin = S ** 3 * self.ch
+        ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, lin, self.L, self.dt))
+        t = self._empty(B, lin)
+        L.call('vv_dense_fwd', L.ptr(z_act), L.ptr(pk['wd']), L.ptr(pk['scaled']), L.ptr(pk['shiftd']), L.ptr(t), B, lin,
+               self.L, self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
+        n0 = S ** 3 * f[0]
+        ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, n0, lin, self.dt))
+        h = self._empty(B, S, S, S, f[0])
+        L.call('vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
+               self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
+        side = S
+        for i in range(1, len(f) - 1):
+            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))
+            o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+            L.call('vv_convT3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                   L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+            h, side = o, 2 * side
+        if target is None:
+            target = torch.zeros(B, D, D, D, 1, dtype=torch.float32, device=self.device)
+        elif target.dtype != torch.float32 or target.numel() != B * D ** 3 or not target.is_contiguous():
+            raise ValueError('target must be contiguous float32 [B,%d,%d,%d,1]' % (D, D, D))
+        probs = self._empty(B, D, D, D, 1, dtype=torch.float32) if self.final_sigmoid else None
+        logits = self._empty(B, D, D, D, 1, dtype=torch.float32) if (want_logits or not self.final_sigmoid) else None
+        stats = self._empty(B, 4, dtype=torch.float32)
+        ws = self.ws.get(L.load().vv_convT3d_final_bce_workspace_bytes(B, side))
+        L.call('vv_convT3d_final_bce_fwd', L.ptr(h), L.ptr(self.params['convT%d/kernel' % (len(f) - 1)]), L.ptr(target),
+               L.ptr(probs), L.ptr(logits), L.ptr(stats), B, side, f[-2], gamma, epsilon, self.dt, L.ptr(ws), ws.numel(), st)
+        return (probs if self.final_sigmoid else logits), logits, stats
+
+
+def reparam_kl(enc_out, eps, latent, act_dtype, drop_mask=None, drop_scale=1.0, want_stats=False):
+    """Fused slice|clip|sampling|dropout|KL (nolbo.py:1417-1431; function.py:35-38, 84-98)."""
+    B = enc_out.shape[0]
+    dev = enc_out.device
+    z = torch.empty(B, latent, dtype=torch.float32, device=dev)
+    z_act = z if act_dtype == L.VV_F32 else torch.empty(B, latent, dtype=torch.bfloat16, device=dev)
+    kl = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = torch.empty_like(z) if want_stats else None
+    logvar = torch.empty_like(z) if want_stats else None
+    L.call('vv_reparam_kl_fwd', L.ptr(enc_out), L.ptr(eps), L.ptr(drop_mask), float(drop_scale), L.ptr(z),
+           L.ptr(z_act) if act_dtype != L.VV_F32 else None, act_dtype, L.ptr(kl), L.ptr(mean), L.ptr(logvar), B, latent,
+           _stream())
+    return z, z_act, kl, mean, logvar
+
+
+def shape_metrics(stats):
+    """[B,4] (bce,TP,FP,FN) -> float32 [4] = (mean bce, precision, recall, IoU) -- nolbo.py:1498-1501."""
+    out = torch.empty(4, dtype=torch.float32, device=stats.device)
+    L.call('vv_shape_metrics', L.ptr(stats), L.ptr(out), stats.shape[0], _stream())
+    return out

@@ -1,0 +1,75 @@
+"""ctypes binding of lib/libvoxvae.so (the C ABI declared in include/voxvae.h).
+
+There is NO fallback: if the HIP library is missing or a call returns a non-zero status this
+module raises.  Nothing here (or anywhere in the package) imports oracle/.
+"""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae.so')
+
+VV_F32, VV_BF16 = 0, 1
+ACT = {None: 0, 'None': 0, 'linear': 0, 'elu': 1, 'relu': 2, 'lrelu': 3}
+DTYPES = {'f32': VV_F32, 'fp32': VV_F32, 'float32': VV_F32, 'bf16': VV_BF16, 'bfloat16': VV_BF16}
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/voxvae.h one to one (tests/test_abi.py checks the header)
+SIGNATURES = {
+    'vv_abi_version': (_i, []),
+    'vv_status_string': (ctypes.c_char_p, [_i]),
+    'vv_pack_conv_k4': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_pack_convT_k4s2': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_pack_conv_k4s1_meanpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'vv_pack_convT_k4s1_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'vv_pack_dense': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_fold_bn': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
+    'vv_conv3d_first_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'vv_conv3d_k4s2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'vv_conv3d_k4s2_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_convT3d_k4s2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'vv_convT3d_k4s2_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_dense_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'vv_dense_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_reparam_kl_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    'vv_convT3d_final_bce_workspace_bytes': (_sz, [_i, _i]),
+    'vv_convT3d_final_bce_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
+    'vv_shape_metrics': (_i, [_vp, _vp, _i, _vp]),
+}
+
+
+class VoxVaeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the library (once).  Raises VoxVaeError when it has not been built -- by design."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VoxVaeError('HIP library missing: %s (run `python __graft_entry__.py` / voxvae/build.py); '
+                              'there is no CPU fallback' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise VoxVaeError('%s failed: %s (%d)' % (what, load().vv_status_string(status).decode(), status))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,124 @@
+/* voxvae.h -- C ABI of libvoxvae.so: the MI355X (gfx950) voxel VAE reconstruction hot path.
+ *
+ * The reference (bogus2000/anytime-3D-reconstruction) has NO FFI / plugin / operator interface: it is
+ * Python on TensorFlow and its seam is the Python API of src/net_core + src/module.  The
+ * drop-in for that seam is the Python package in anytime-3d-reconstruction_amd/src/ (same module paths, names,
+ * signatures).  This header is the boundary UNDER that package: what a maintainer of the reference would bind
+ * (ctypes stub in INTEGRATION.md) to replace the TensorFlow ops each function cites.  Citations are
+ * /root/reference paths.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense, channels-last
+ *     (NDHWC), cubic grids with a power-of-two side; `stream` is a hipStream_t passed as void*.
+ *   - activations/weights are VV_F32 or VV_BF16 (`dtype`); statistics, losses, logits, probabilities, latents
+ *     are always float32.
+ *   - functions return 0 (VV_OK) or a negative vv_status; they never throw, never allocate, never
+ *     synchronise; scratch comes from the caller (`*_workspace_bytes`).  No global state: thread-safe per stream.
+ */
+#ifndef VOXVAE_H
+#define VOXVAE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { VV_F32 = 0, VV_BF16 = 1 } vv_dtype;
+typedef enum { VV_ACT_NONE = 0, VV_ACT_ELU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 } vv_act;
+typedef enum {
+    VV_OK = 0,
+    VV_ERR_NULL = -1,       /* required pointer is NULL */
+    VV_ERR_SHAPE = -2,      /* unsupported / inconsistent shape */
+    VV_ERR_DTYPE = -3,
+    VV_ERR_ALIGN = -4,      /* pointer not 16-byte aligned */
+    VV_ERR_WORKSPACE = -5,  /* workspace too small */
+    VV_ERR_LAUNCH = -6      /* hipGetLastError() != hipSuccess after launch */
+} vv_status;
+
+int vv_abi_version(void);
+const char *vv_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Weight packing: Keras variable layouts -> the K-contiguous [N][K] panels the MFMA kernels stream.
+ * One-off per weight update; device to device. */
+
+/* Conv3D kernel [4,4,4,Cin,Cout] (autoencoder3D.py:27) -> packed [Cout][64*Cin], k = tap*Cin + ci. */
+int vv_pack_conv_k4(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream);
+/* Conv3DTranspose kernel [4,4,4,Cout,Cin] (autoencoder3D.py:42) stride 2 -> 8 output-parity panels
+ * packed [8][Cout][8*Cin]; parity p = (pd,ph,pw), k = (ad,ah,aw)*Cin + ci, tap t = 1 - p + 2a per axis. */
+int vv_pack_convT_k4s2(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream);
+/* Final encoder Conv3D k4 s1 SAME (pad 1/2) followed by the spatial mean (autoencoder3D.py:86-91) is linear in
+ * its input: packed [Cout][S^3*Cin] with W_eff[i] = (1/S^3) * sum_o w[i - o + 1]  (S = input side). */
+int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);
+/* First decoder Conv3DTranspose k4 s1 SAME on the S^3 x Cin seed (autoencoder3D.py:127-128, first loop
+ * iteration) as one dense panel: packed [S^3*Cout][S^3*Cin], row (o,co), col (j,ci) = w[o - j + 1][co][ci]. */
+int vv_pack_convT_k4s1_dense(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);
+/* Dense kernel [In,Out] (autoencoder3D.py:59) -> packed [Out][In]. */
+int vv_pack_dense(const float *w_keras, void *packed, int in, int out, int dtype, void *stream);
+/* BatchNormalization(training=False) folded to y = x*scale + shift (autoencoder3D.py:31,46,62):
+ * scale = gamma/sqrt(var+eps); shift = beta + (bias - mean)*scale.  bias may be NULL.  `repeat` tiles the C
+ * channel vector (used when a spatial layer is run as one dense panel). */
+int vv_fold_bn(const float *gamma, const float *beta, const float *mean, const float *var, const float *bias,
+               float eps, float *scale, float *shift, int channels, int repeat, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Layers (inference form: conv -> folded BN -> activation).  scale/shift may be NULL (identity). */
+
+/* conv3DEnc with Cin = 1: Conv3D k4 s2 SAME on the occupancy grid + BN + act (autoencoder3D.py:26-39, first
+ * loop iteration :84-85).  x [B,D,D,D,1] float32; w_keras [4,4,4,1,Cout] float32 (used as is);
+ * y [B,D/2,D/2,D/2,Cout] dtype. */
+int vv_conv3d_first_fwd(const float *x, const float *w_keras, const float *scale, const float *shift, void *y,
+                        int batch, int side, int cout, int act, int dtype, void *stream);
+
+/* conv3DEnc, Cin % 64 == 0: Conv3D k4 s2 SAME + BN + act as an implicit GEMM on MFMA
+ * (autoencoder3D.py:26-39).  x [B,D,D,D,Cin]; w = vv_pack_conv_k4; y [B,D/2,...,Cout]. */
+size_t vv_conv3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype);
+int vv_conv3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                       int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* conv3DDec stride 2: Conv3DTranspose k4 s2 SAME + BN + act as 8 output-parity implicit GEMMs
+ * (autoencoder3D.py:41-54).  x [B,D,D,D,Cin]; w = vv_pack_convT_k4s2; y [B,2D,2D,2D,Cout]. */
+size_t vv_convT3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype);
+int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                        int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
+ * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).
+ * out_dtype may differ from dtype (the encoder output is float32). */
+size_t vv_dense_workspace_bytes(int m, int n, int k, int dtype);
+int vv_dense_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y, int m, int n,
+                 int k, int act, int dtype, int out_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Latent ops */
+
+/* slice | clip(-10,10) | sampling | Dropout | kl_loss vs N(0,I), fused (nolbo.py:1417-1431, 1464-1470;
+ * function.py:35-38, 84-98).  enc_out [B,2L]; eps [B,L] (the tf.random.normal draw, injected);
+ * drop_mask [B,L] in {0,1} or NULL, drop_scale = 1/(1-rate); z [B,L] float32; z_act [B,L] = the same values in
+ * the activation dtype `act_dtype` that feeds the decoder (may be NULL); kl [B] (may be NULL); mean/logvar [B,L]
+ * outputs may be NULL. */
+int vv_reparam_kl_fwd(const float *enc_out, const float *eps, const float *drop_mask, float drop_scale, float *z,
+                      void *z_act, int act_dtype, float *kl, float *mean, float *logvar, int batch, int latent,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Decoder tail + losses, fused: Conv3DTranspose k4 s2 SAME -> 1 channel (logits), tf.sigmoid, binary_loss
+ * (gamma, epsilon clip) and voxelPrecisionRecall at p >= 0.5 (autoencoder3D.py:129-136; function.py:73-82,
+ * 100-115; nolbo.py:1496-1499).  x [B,D,D,D,Cin] dtype; w_keras [4,4,4,1,Cin] float32; target [B,2D,2D,2D]
+ * float32; probs/logits [B,2D,2D,2D] float32 (either may be NULL); stats [B,4] = per-sample (bce,TP,FP,FN). */
+size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side);
+int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *target, float *probs, float *logits,
+                             float *stats, int batch, int side, int cin, float gamma, float epsilon, int dtype,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* Batch means of nolbo.py:1498-1501: out[0..3] = mean_b bce, mean_b TP/(TP+FP+1e-10), mean_b TP/(TP+FN+1e-10),
+ * mean_b TP/max(TP+FP+FN,1) (IoU: not in the reference). */
+int vv_shape_metrics(const float *stats, float *out4, int batch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

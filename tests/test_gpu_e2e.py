@@ -1,0 +1,101 @@
+"""GPU end-to-end parity: encoder -> reparam -> decoder -> BCE/TP/FP/FN through the engines, against the
+committed golden fixtures (fp64 numpy oracle) and the fp32 C oracle.
+Bars (BASELINE.json north_star): f32 mode -- logits within 1e-3 and occupancy (logit >= 0) identical outside a
+1e-4 guard band around the threshold; bf16 mode -- mean IoU within 1e-3 of the oracle's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import numpy_oracle as no
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DEV = 'cuda:0'
+
+
+def _run(cfg, ep, dp, x, y, eps, dtname, variational=True):
+    from voxvae import engine as E
+    from voxvae import lib as L
+    enc = E.EncoderEngine(cfg['encoder'], dtname, DEV)
+    dec = E.DecoderEngine(cfg['decoder'], dtname, DEV)
+    enc.set_params(ep)
+    dec.set_params(dp)
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.from_numpy(y).to(DEV)
+    enc_out = enc.forward(xd)
+    Lz = cfg['z_category_dim']
+    if variational:
+        z, z_act, kl, _, _ = E.reparam_kl(enc_out, torch.from_numpy(eps).to(DEV), Lz, enc.dt)
+    else:
+        z, kl = enc_out, None
+        z_act = enc_out if enc.dt == L.VV_F32 else enc_out.to(torch.bfloat16)
+    probs, logits, stats = dec.forward(z_act, yd, want_logits=True)
+    m = E.shape_metrics(stats)
+    torch.cuda.synchronize()
+    return {'enc_out': enc_out.cpu().numpy(), 'z': z.cpu().numpy(), 'kl': None if kl is None else kl.cpu().numpy(),
+            'logits': logits.cpu().numpy(), 'probs': probs.cpu().numpy(), 'stats': stats.cpu().numpy(),
+            'metrics': m.cpu().numpy()}
+
+
+def _case(name):
+    from voxvae import synthetic as syn
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    D, Lz, var, B, C = [int(v) for v in g['meta'][:5]]
+    cfg = syn.make_config(D, Lz, bool(var))
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    return g, cfg, ep, dp, syn.make_voxels(B, D), syn.make_eps(B, Lz), bool(var)
+
+
+@pytest.mark.parametrize('name', ['vae_d32_l64_b2', 'ae_d32_l64_b2', 'vae_d16_l64_b3', 'vae_d64_l16_b1'])
+def test_f32_matches_golden(name):
+    g, cfg, ep, dp, x, eps, var = _case(name)
+    r = _run(cfg, ep, dp, x, x, eps, 'f32', var)
+    np.testing.assert_allclose(r['enc_out'], g['p0_enc_out'], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(r['z'], g['p0_z'], rtol=0, atol=2e-5)
+    if var:
+        np.testing.assert_allclose(r['kl'], g['p0_kl'], rtol=2e-5, atol=1e-6)
+    lg = g['p0_logits'].astype(np.float64)
+    err = np.abs(r['logits'] - lg).max()
+    assert err < 1e-3, 'logit error %.3e exceeds the 1e-3 bar' % err
+    safe = np.abs(lg) > 1e-4
+    assert np.array_equal((r['logits'] >= 0)[safe], (lg >= 0)[safe]), 'occupancy differs outside the guard band'
+    nflip = int(((r['logits'] >= 0) != (lg >= 0)).sum())
+    np.testing.assert_allclose(r['stats'][:, 0], g['p0_bce'], rtol=1e-4)
+    for k, key in ((1, 'p0_tp'), (2, 'p0_fp'), (3, 'p0_fn')):
+        assert np.abs(r['stats'][:, k] - g[key]).max() <= nflip
+    print('\n[%s f32] max|dlogit| %.3e  flips %d' % (name, err, nflip))
+
+
+@pytest.mark.parametrize('name', ['vae_d32_l64_b2', 'vae_d16_l64_b3', 'vae_d64_l16_b1'])
+def test_bf16_iou_delta(name):
+    g, cfg, ep, dp, x, eps, var = _case(name)
+    r = _run(cfg, ep, dp, x, x, eps, 'bf16', var)
+    iou_ref = no.iou(g['p0_tp'], g['p0_fp'], g['p0_fn'])
+    s = r['stats'].astype(np.float64)
+    iou_gpu = no.iou(s[:, 1], s[:, 2], s[:, 3])
+    d = abs(iou_gpu.mean() - iou_ref.mean())
+    lg = g['p0_logits'].astype(np.float64)
+    err = np.abs(r['logits'] - lg).max()
+    print('\n[%s bf16] IoU ref %.6f gpu %.6f delta %.2e ; max|dlogit| %.3e (max|logit| %.2f)' %
+          (name, iou_ref.mean(), iou_gpu.mean(), d, err, np.abs(lg).max()))
+    assert d <= 1e-3
+    assert err < 0.05 * np.abs(lg).max()
+
+
+def test_f32_batch_invariance_and_c_oracle():
+    """Same samples inside a larger batch give the same logits (tile/split-K choices change with M, so equality is
+    to rounding), and agree with the fp32 C restatement on samples the golden set does not hold."""
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(32, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x = syn.make_voxels(16, 32, seed=99)
+    eps = syn.make_eps(16, 64, seed=17)
+    big = _run(cfg, ep, dp, x, x, eps, 'f32')
+    small = _run(cfg, ep, dp, x[:3], x[:3], eps[:3], 'f32')
+    assert np.abs(big['logits'][:3] - small['logits']).max() < 2e-5
+    c = co.vae_eval_forward(cfg, ep, dp, x[12:], x[12:], eps[12:])
+    assert np.abs(big['logits'][12:] - c['logits']).max() < 1e-3
+    np.testing.assert_allclose(big['stats'][12:, 0], c['bce'], rtol=1e-4)
