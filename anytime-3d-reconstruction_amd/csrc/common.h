@@ -20,7 +20,20 @@ static inline int vv_log2(int v) {
 }
 static inline bool vv_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t vv_dtype_size(int dt) { return dt == VV_BF16 ? 2 : 4; }
-static inline int vv_launch_status() { return hipGetLastError() == hipSuccess ? VV_OK : VV_ERR_LAUNCH; }
+// hipGetLastError() is per-thread and may hold a stale error from the host framework: clear it, then launch.
+#define VV_LAUNCH(...)            \
+    do {                          \
+        (void)hipGetLastError();  \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
+extern thread_local int vv_tls_last_hip_error;  // small.hip; read through vv_last_hip_error()
+static inline int vv_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return VV_OK;
+    vv_tls_last_hip_error = (int)e;
+    return VV_ERR_LAUNCH;
+}
 
 // autoencoder3D.py:33-38: ELU(alpha 1) / ReLU / LeakyReLU(alpha 0.3, the Keras default)
 __device__ __forceinline__ float vv_apply_act(float v, int act) {

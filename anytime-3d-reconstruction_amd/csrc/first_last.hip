@@ -1,87 +1,9 @@
-// The two HBM-bound ends of the path (gfx950):
-//   conv_first : Conv3D k4 s2 SAME with Cin = 1 on the float32 occupancy grid + BN + act   (autoencoder3D.py:26-39)
+// The HBM-bound tail of the path (gfx950):
 //   final_bce  : Conv3DTranspose k4 s2 SAME -> 1 channel, sigmoid, weighted BCE and TP/FP/FN, fused
 //                (autoencoder3D.py:129-136; function.py:73-82, 100-115)
 #include "common.h"
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------------------------
-// conv_first.  4 lanes share one output voxel (16 output channels each); the 4x4x4 window of x is read through L1
-// (each x value is a wave-level broadcast to the 4 lanes and is re-read by the 8 neighbouring windows), the
-// [64 taps][Cout] weights live in LDS and are read as float4 broadcasts.  Output is the dominant stream:
-// Cout*sizeof(T) contiguous bytes per voxel.
-template <typename T, int COUT>
-__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                         T *__restrict__ y, int batch, int din_log2, int act) {
-    constexpr int G = COUT / 16;         // lanes per voxel
-    constexpr int VPB = 256 / G;         // voxels per pass
-    __shared__ __attribute__((aligned(16))) float wl[64 * COUT];
-    for (int i = threadIdx.x; i < 64 * COUT; i += 256) wl[i] = w[i];
-    __syncthreads();
-    const int li = din_log2, lo = li - 1, n = 1 << li, msk = (1 << lo) - 1;
-    const int g = threadIdx.x % G, vl = threadIdx.x / G;
-    const long nvox = (long)batch << (3 * lo);
-    float sc[16], sh[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        sc[c] = scale ? scale[g * 16 + c] : 1.f;
-        sh[c] = shift ? shift[g * 16 + c] : 0.f;
-    }
-    for (long v0 = (long)blockIdx.x * VPB; v0 < nvox; v0 += (long)gridDim.x * VPB) {
-        const long v = v0 + vl;
-        if (v >= nvox) continue;
-        const int ow = (int)(v & msk), oh = (int)((v >> lo) & msk), od = (int)((v >> (2 * lo)) & msk);
-        const long b = v >> (3 * lo);
-        const float *xb = x + (b << (3 * li));
-        float acc[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int td = 0; td < 4; ++td) {
-            const int id = 2 * od - 1 + td;
-#pragma unroll
-            for (int th = 0; th < 4; ++th) {
-                const int ih = 2 * oh - 1 + th;
-                const bool rowok = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n;
-#pragma unroll
-                for (int tw = 0; tw < 4; ++tw) {
-                    const int iw = 2 * ow - 1 + tw;
-                    const float xv = (rowok && (unsigned)iw < (unsigned)n) ? xb[(((long)id << li) + ih << li) + iw] : 0.f;
-                    const f32x4 *wp = reinterpret_cast<const f32x4 *>(wl + ((td * 4 + th) * 4 + tw) * COUT + g * 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 wv = wp[q];
-                        acc[q * 4 + 0] = fmaf(xv, wv[0], acc[q * 4 + 0]);
-                        acc[q * 4 + 1] = fmaf(xv, wv[1], acc[q * 4 + 1]);
-                        acc[q * 4 + 2] = fmaf(xv, wv[2], acc[q * 4 + 2]);
-                        acc[q * 4 + 3] = fmaf(xv, wv[3], acc[q * 4 + 3]);
-                    }
-                }
-            }
-        }
-        T *yp = y + v * COUT + g * 16;
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 o0, o1;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                o0[c] = static_cast<__bf16>(vv_apply_act(acc[c] * sc[c] + sh[c], act));
-                o1[c] = static_cast<__bf16>(vv_apply_act(acc[8 + c] * sc[8 + c] + sh[8 + c], act));
-            }
-            reinterpret_cast<bf16x8 *>(yp)[0] = o0;
-            reinterpret_cast<bf16x8 *>(yp)[1] = o1;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = vv_apply_act(acc[q * 4 + c] * sc[q * 4 + c] + sh[q * 4 + c], act);
-                reinterpret_cast<f32x4 *>(yp)[q] = o;
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // final_bce.  One workgroup = a 4x4x4 block of input-grid cells (-> 8x8x8 logits) of one sample.  The 6x6x6 input
@@ -198,26 +120,6 @@ __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restric
 
 }  // namespace
 
-VV_EXPORT int vv_conv3d_first_fwd(const float *x, const float *w_keras, const float *scale, const float *shift, void *y,
-                                  int batch, int side, int cout, int act, int dtype, void *stream) {
-    if (!x || !w_keras || !y) return VV_ERR_NULL;
-    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (batch <= 0 || side < 4 || !vv_is_pow2(side) || cout != 64) return VV_ERR_SHAPE;
-    if (!vv_aligned16(y)) return VV_ERR_ALIGN;
-    const int li = vv_log2(side);
-    const long nvox = (long)batch << (3 * (li - 1));
-    long blocks = (nvox + 255) / 256;  // 4 passes of 64 voxels per workgroup
-    if (blocks < 1) blocks = 1;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == VV_BF16)
-        hipLaunchKernelGGL((conv_first_kernel<__bf16, 64>), dim3((unsigned)blocks), dim3(256), 0, st, x, w_keras, scale, shift,
-                           reinterpret_cast<__bf16 *>(y), batch, li, act);
-    else
-        hipLaunchKernelGGL((conv_first_kernel<float, 64>), dim3((unsigned)blocks), dim3(256), 0, st, x, w_keras, scale, shift,
-                           reinterpret_cast<float *>(y), batch, li, act);
-    return vv_launch_status();
-}
-
 VV_EXPORT size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side) {
     const size_t nb = side / 4;
     return (size_t)batch * nb * nb * nb * 4 * sizeof(float);
@@ -237,11 +139,11 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *partials = reinterpret_cast<float *>(workspace);
     if (dtype == VV_BF16)
-        hipLaunchKernelGGL((final_bce_kernel<__bf16>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x),
+        VV_LAUNCH((final_bce_kernel<__bf16>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
     else
-        hipLaunchKernelGGL((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+        VV_LAUNCH((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
-    hipLaunchKernelGGL(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
+    VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
     return vv_launch_status();
 }

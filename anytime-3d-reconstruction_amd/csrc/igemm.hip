@@ -7,6 +7,9 @@
 // MODE_CONVT : Conv3DTranspose k4 s2 SAME as 8 output-parity sub-convolutions, rows = INPUT-grid cells,
 //              k = (tap 2x2x2, ci), blockIdx.z = parity                          -- autoencoder3D.py:41-54
 //
+// MODE_FIRST: Conv3D k4 s2 SAME with Cin = 1 on the float32 occupancy grid: K = the 64 taps of the 4x4x4 window,
+//              gathered element-wise from x (two 4-voxel runs per 16-byte slot) and converted on the fly
+//
 // Channels-last makes every K chunk of one row a contiguous 128-byte segment (or zeros, for a tap in the
 // SAME padding), so both operands are staged as [rows][128 B] LDS images, XOR-swizzled per 16-byte slot so the
 // ds_read_b128 fragment reads are bank-conflict free, and consumed by v_mfma_f32_32x32x16_bf16 (bf16) or
@@ -17,7 +20,7 @@
 
 namespace {
 
-enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_CONVT = 2 };
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_CONVT = 2, MODE_FIRST = 3 };
 
 struct IgemmArgs {
     const void *A;
@@ -62,7 +65,7 @@ __device__ __forceinline__ RowCtx make_row(const IgemmArgs &a, int m, int parity
     }
     const int li = a.din_log2, n = 1 << li;
     int b;
-    if (MODE == MODE_CONV) {
+    if (MODE == MODE_CONV || MODE == MODE_FIRST) {
         const int lo = li - 1, msk = (1 << lo) - 1;
         const int ow = m & msk, oh = (m >> lo) & msk, od = (m >> (2 * lo)) & msk;
         b = m >> (3 * lo);
@@ -80,7 +83,7 @@ __device__ __forceinline__ RowCtx make_row(const IgemmArgs &a, int m, int parity
 // element offset of (row, chunk kc) and its validity
 template <int MODE, int BK>
 __device__ __forceinline__ bool row_chunk(const IgemmArgs &a, const RowCtx &r, int kc, int chunk, int &off) {
-    if (MODE == MODE_DENSE) {  // K tail: 16-byte slots past K read as zero (K % slot == 0)
+    if (MODE == MODE_DENSE || MODE == MODE_FIRST) {  // K tail (MODE_FIRST gathers in gload itself): 16-byte slots past K read as zero (K % slot == 0)
         off = r.off0 + kc * BK;
         return r.ok && kc * BK + chunk * (BK / 8) < a.K;
     }
@@ -157,11 +160,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     uint4 ra[RA], rb[RB];
     auto gload = [&](int kc) {
+        if constexpr (MODE == MODE_FIRST) {
+            // slot `chunk` of K chunk kc holds 16/sizeof(T) consecutive taps t = (td*4 + th)*4 + tw of the window
+            constexpr int EPS = 16 / (int)sizeof(T);
+            const int n = 1 << a.din_log2;
+            const float *xf = reinterpret_cast<const float *>(a.A);
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                T vals[EPS];
+#pragma unroll
+                for (int e = 0; e < EPS; ++e) {
+                    const int t = kc * BK + chunk * EPS + e;
+                    const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
+                    const bool ok = rows[i].ok && (unsigned)(rows[i].d0 + td) < (unsigned)n &&
+                                    (unsigned)(rows[i].h0 + th) < (unsigned)n && (unsigned)(rows[i].w0 + tw) < (unsigned)n;
+                    const float v = ok ? xf[rows[i].off0 + ((td << a.din_log2) + th << a.din_log2) + tw] : 0.f;
+                    vals[e] = static_cast<T>(v);
+                }
+                ra[i] = *reinterpret_cast<const uint4 *>(vals);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int off;
             const bool v = row_chunk<MODE, BK>(a, rows[i], kc, chunk, off);
             ra[i] = v ? *reinterpret_cast<const uint4 *>(Ab + (long)off * (long)sizeof(T) + chunk * 16) : make_uint4(0, 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -298,12 +322,12 @@ int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
         return true;
     }();
     (void)attr_set;
-    if (p.bn == 128) hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, 128>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((igemm_kernel<T, MODE, 128, 64>), grid, dim3(256), lds, st, a);
+    if (p.bn == 128) VV_LAUNCH((igemm_kernel<T, MODE, 128, 128>), grid, dim3(256), lds, st, a);
+    else VV_LAUNCH((igemm_kernel<T, MODE, 128, 64>), grid, dim3(256), lds, st, a);
     if (p.split > 1) {
         const size_t total = (size_t)p.nparity * a.M * (a.N / 4);
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL((igemm_splitk_epilogue<MODE>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity);
+        VV_LAUNCH((igemm_splitk_epilogue<MODE>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity);
     }
     return vv_launch_status();
 }
@@ -316,7 +340,8 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     const int bk = dtype == VV_BF16 ? 64 : 32;
     if (M <= 0 || N <= 0 || K <= 0 || N % 4) return VV_ERR_SHAPE;
     if (mode == MODE_DENSE ? (K % (bk / 8)) != 0 : (K % bk) != 0) return VV_ERR_SHAPE;
-    if (mode != MODE_DENSE && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
+    if (mode == MODE_FIRST && (!vv_is_pow2(din) || cin != 1)) return VV_ERR_SHAPE;
+    if ((mode == MODE_CONV || mode == MODE_CONVT) && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const Plan p = make_plan(mode, M, N, K, dtype);
     if (p.split > 1 && (!ws || ws_bytes < p.ws_bytes || !vv_aligned16(ws))) return VV_ERR_WORKSPACE;
@@ -327,12 +352,13 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     a.M = M; a.N = N; a.K = K;
     a.din_log2 = mode == MODE_DENSE ? 0 : vv_log2(din);
     a.cin = cin;
-    a.cpt_log2 = mode == MODE_DENSE ? 0 : vv_log2(cin / bk);
+    a.cpt_log2 = (mode == MODE_DENSE || mode == MODE_FIRST) ? 0 : vv_log2(cin / bk);
     a.nchunks = (K + bk - 1) / bk;
     a.chunks_per_split = p.cps;
     a.act = act;
     a.out_bf16 = out_dtype == VV_BF16;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mode == MODE_FIRST) return dtype == VV_BF16 ? launch_t<__bf16, MODE_FIRST>(a, p, st) : launch_t<float, MODE_FIRST>(a, p, st);
     if (dtype == VV_BF16) {
         if (mode == MODE_DENSE) return launch_t<__bf16, MODE_DENSE>(a, p, st);
         if (mode == MODE_CONV) return launch_t<__bf16, MODE_CONV>(a, p, st);
@@ -381,4 +407,14 @@ VV_EXPORT int vv_dense_fwd(const void *x, const void *w_packed, const float *sca
     if ((long)m * k >= (1L << 31)) return VV_ERR_SHAPE;
     return run_igemm(MODE_DENSE, x, w_packed, scale, shift, y, m, n, k, 0, 0, act, dtype, out_dtype, workspace,
                      workspace_bytes, stream);
+}
+
+// Cin = 1 first layer on the same MFMA tile engine: w_packed = vv_pack_conv_k4(cin = 1) = [Cout][64 taps].
+VV_EXPORT int vv_conv3d_first_fwd(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                  int batch, int side, int cout, int act, int dtype, void *stream) {
+    if (batch <= 0 || side < 2 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
+    if ((long)batch * side * side * side >= (1L << 31)) return VV_ERR_SHAPE;
+    const int o = side / 2;
+    return run_igemm(MODE_FIRST, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64, side, 1, act, dtype, dtype, nullptr,
+                     0, stream);
 }

@@ -159,15 +159,19 @@ inline int grid_for(size_t total) {
         if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;                                          \
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                \
         if (dtype == VV_BF16)                                                                                  \
-            hipLaunchKernelGGL((KERNEL<__bf16>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,             \
+            VV_LAUNCH((KERNEL<__bf16>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,             \
                                reinterpret_cast<__bf16 *>(packed), __VA_ARGS__);                               \
         else                                                                                                   \
-            hipLaunchKernelGGL((KERNEL<float>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,              \
+            VV_LAUNCH((KERNEL<float>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,              \
                                reinterpret_cast<float *>(packed), __VA_ARGS__);                                \
         return vv_launch_status();                                                                             \
     } while (0)
 
+thread_local int vv_tls_last_hip_error = 0;
+
 VV_EXPORT int vv_abi_version(void) { return 1; }
+
+VV_EXPORT const char *vv_last_hip_error(void) { return hipGetErrorString((hipError_t)vv_tls_last_hip_error); }
 
 VV_EXPORT const char *vv_status_string(int s) {
     switch (s) {
@@ -214,7 +218,7 @@ VV_EXPORT int vv_fold_bn(const float *gamma, const float *beta, const float *mea
                          float eps, float *scale, float *shift, int channels, int repeat, void *stream) {
     if (!gamma || !beta || !mean || !var || !scale || !shift) return VV_ERR_NULL;
     if (channels <= 0 || repeat <= 0) return VV_ERR_SHAPE;
-    hipLaunchKernelGGL(fold_bn_kernel, dim3(grid_for((size_t)channels * repeat)), dim3(256), 0,
+    VV_LAUNCH(fold_bn_kernel, dim3(grid_for((size_t)channels * repeat)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), gamma, beta, mean, var, bias, eps, scale, shift, channels,
                        repeat);
     return vv_launch_status();
@@ -229,10 +233,10 @@ VV_EXPORT int vv_reparam_kl_fwd(const float *enc_out, const float *eps, const fl
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((batch + 3) / 4), block(256);
     if (z_act && act_dtype == VV_BF16)
-        hipLaunchKernelGGL((reparam_kl_kernel<__bf16>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
+        VV_LAUNCH((reparam_kl_kernel<__bf16>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
                            reinterpret_cast<__bf16 *>(z_act), kl, mean, logvar, batch, latent);
     else
-        hipLaunchKernelGGL((reparam_kl_kernel<float>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
+        VV_LAUNCH((reparam_kl_kernel<float>), grid, block, 0, st, enc_out, eps, drop_mask, drop_scale, z,
                            reinterpret_cast<float *>(z_act), kl, mean, logvar, batch, latent);
     return vv_launch_status();
 }
@@ -240,6 +244,6 @@ VV_EXPORT int vv_reparam_kl_fwd(const float *enc_out, const float *eps, const fl
 VV_EXPORT int vv_shape_metrics(const float *stats, float *out4, int batch, void *stream) {
     if (!stats || !out4) return VV_ERR_NULL;
     if (batch <= 0) return VV_ERR_SHAPE;
-    hipLaunchKernelGGL(shape_metrics_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), stats, out4, batch);
+    VV_LAUNCH(shape_metrics_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), stats, out4, batch);
     return vv_launch_status();
 }

@@ -1,0 +1,219 @@
+"""Drop-in for the ModelNet model classes of the reference's src/module/nolbo.py:
+
+    nolboSingleObject_modelnet_category_AE    (reference nolbo.py:1206-1385)
+    nolboSingleObject_modelnet_category_VAE   (reference nolbo.py:1387-1592)
+
+Same constructor arguments, methods, argument meaning and return tuples; the arithmetic is the MI355X HIP
+library.  Host inputs are numpy float32 NDHWC arrays exactly as the reference's data loader produces
+(src/dataset_loader/modelnet_dataset.py:83); device-resident torch tensors / DeviceArrays are accepted too and
+skip the host->device copy.
+
+The reference draws three random tensors inside these methods (the sampling epsilon, nolbo.py:1470; the
+np.random mask, :1475; the prior epsilon, :1508) and the dropout rate/mask (:1423-1425).  They are drawn here
+the same way by default (mask through np.random.choice with the same arguments, so seeding np.random
+reproduces the reference's mask stream); the keyword-only `_eps`, `_mask`, `_eps2` arguments (an extension)
+inject them, which is what makes bit-level parity tests possible.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+import src.net_core.autoencoder3D as ae3D
+from voxvae import engine as _E
+from voxvae import lib as _L
+from voxvae.tensor import DeviceArray, as_device_f32
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _ModelnetBase(object):
+    _variational = True
+
+    def _buildModel(self):
+        print('build Models...')
+        self._encoder = ae3D.encoder3D(structure=self._enc_str)
+        # ==============set decoder3D
+        self._decoder = ae3D.decoder3D(structure=self._dec_str)
+        self._enc_eng, self._dec_eng = self._encoder._engine, self._decoder._engine
+        self._device = self._enc_eng.device
+        self._act_dt = self._dec_eng.dt
+        print('done')
+
+    # ---------------------------------------------------------------- device-side building blocks
+    def _dev(self, a):
+        return as_device_f32(a, self._device)
+
+    def _to_act(self, z):
+        return z if self._act_dt == _L.VV_F32 else z.to(torch.bfloat16)
+
+    def _encode_latent(self, x, eps=None, want_kl=False):
+        """encoder -> (slice | clip | sampling) for the VAE, identity for the AE.  Returns (z, z_act, kl)."""
+        enc_out = self._enc_eng.forward(x)
+        if not self._variational:
+            return enc_out, self._to_act(enc_out), None
+        Lz = self._enc_backbone_str['z_category_dim']
+        if enc_out.shape[1] != 2 * Lz:
+            raise ValueError('VAE encoder must emit 2*z_category_dim channels, got %d' % enc_out.shape[1])
+        eps = torch.randn(x.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
+        z, z_act, kl, _, _ = _E.reparam_kl(enc_out, eps, Lz, self._act_dt)
+        return z, z_act, kl
+
+    def _decode_metrics(self, z_act, target):
+        out, _, stats = self._dec_eng.forward(z_act, target)
+        m = _E.shape_metrics(stats)
+        return out, stats, m
+
+    def _category_acc(self, z, cats, onehot, mask=None):
+        B, Lz, C = z.shape[0], z.shape[1], cats.shape[0]
+        idx = torch.empty(B, dtype=torch.int32, device=self._device)
+        _L.call('vv_nearest_category', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), C, _L.ptr(idx), B, Lz, _st())
+        acc = None
+        if onehot is not None:
+            acc = torch.empty(1, dtype=torch.float32, device=self._device)
+            _L.call('vv_category_accuracy', _L.ptr(idx), _L.ptr(onehot), C, _L.ptr(acc), B, _st())
+        return idx, acc
+
+    # ---------------------------------------------------------------- public API (reference signatures)
+    def getEval(self, inputs, category_vectors=None, training=False, missing_prob=0.0, *, _eps=None, _mask=None, _eps2=None):
+        """reference nolbo.py:1449-1528 (VAE) / :1260-1332 (AE): returns the 10-tuple
+        (pred, loss_shape, pr, rc, acc_cat, pred_corrected, loss_corrected, pr_corrected, rc_corrected, acc_cat_corrected),
+        the last five being 0 when missing_prob == 0.
+        Legacy form still used by the reference's train scripts (train_modelnet_category_VAE.py:83-84, body kept as
+        the commented block nolbo.py:1530-1555): inputs=(x, y) without category_vectors -> (pred, loss_shape, pr, rc)."""
+        if training:
+            raise NotImplementedError('getEval(training=True) is not used by any reference caller')
+        if len(inputs) == 2 or category_vectors is None:
+            return self._getEval_legacy(inputs, missing_prob, _eps, _mask)
+        input_images, output_images, category_list = inputs
+        x, y, onehot = self._dev(input_images), self._dev(output_images), self._dev(category_list)
+        cats = self._dev(category_vectors)
+        B, Lz, C = x.shape[0], self._enc_backbone_str['z_category_dim'], cats.shape[0]
+        z, z_act, _ = self._encode_latent(x, _eps)
+        mask = None
+        if missing_prob > 0:
+            if _mask is None:   # reference nolbo.py:1475-1476, same RNG call
+                _mask = np.reshape(np.random.choice(2, B * Lz, p=[missing_prob, 1. - missing_prob]), [B, Lz]).astype('float32')
+            mask = self._dev(_mask)
+            zf = torch.empty_like(z)
+            zf_act = zf if self._act_dt == _L.VV_F32 else torch.empty(B, Lz, dtype=torch.bfloat16, device=self._device)
+            _L.call('vv_latent_mask_fill', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), C, _L.ptr(zf),
+                    None if zf_act is zf else _L.ptr(zf_act), self._act_dt, B, Lz, _st())
+            z, z_act = zf, zf_act
+        _, acc = self._category_acc(z, cats, onehot)
+        pred, _, m = self._decode_metrics(z_act, y)
+        self._z_category = DeviceArray(z)
+        res = (DeviceArray(pred), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]))
+        if missing_prob == 0.0:
+            return res + (0, 0, 0, 0, 0)
+        idx, _ = self._category_acc(z, cats, None, mask)                          # :1505-1506
+        eps2 = torch.randn(B, Lz, dtype=torch.float32, device=self._device) if _eps2 is None else self._dev(_eps2)
+        zc = torch.empty_like(z)
+        zc_act = zc if self._act_dt == _L.VV_F32 else torch.empty(B, Lz, dtype=torch.bfloat16, device=self._device)
+        _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), _L.ptr(idx), _L.ptr(eps2), _L.ptr(zc),
+                None if zc_act is zc else _L.ptr(zc_act), self._act_dt, B, Lz, _st())  # :1507-1510
+        _, acc_c = self._category_acc(zc, cats, onehot)                           # :1512-1518
+        pred_c, _, mc = self._decode_metrics(zc_act, y)                           # :1520-1527
+        self._z_category_corrected = DeviceArray(zc)
+        return res + (DeviceArray(pred_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
+
+    def _getEval_legacy(self, inputs, missing_prob, _eps, _mask):
+        input_images, output_images = inputs[0], inputs[1]
+        x, y = self._dev(input_images), self._dev(output_images)
+        z, z_act, _ = self._encode_latent(x, _eps)
+        if missing_prob > 0:   # commented body nolbo.py:1544-1548: masked entries become 0
+            B, Lz = z.shape
+            if _mask is None:
+                _mask = np.reshape(np.random.choice(2, B * Lz, p=[missing_prob, 1. - missing_prob]), [B, Lz]).astype('float32')
+            mask = self._dev(_mask)
+            # where(mask == 0, 0, z): the latent_correct kernel with a zero prototype table and zero epsilon
+            zeros = torch.zeros(1, Lz, dtype=torch.float32, device=self._device)
+            idx0 = torch.zeros(B, dtype=torch.int32, device=self._device)
+            e0 = torch.zeros(B, Lz, dtype=torch.float32, device=self._device)
+            zc = torch.empty_like(z)
+            zc_act = zc if self._act_dt == _L.VV_F32 else torch.empty(B, Lz, dtype=torch.bfloat16, device=self._device)
+            _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(zeros), _L.ptr(idx0), _L.ptr(e0), _L.ptr(zc),
+                    None if zc_act is zc else _L.ptr(zc_act), self._act_dt, B, Lz, _st())
+            z_act = zc_act
+        pred, _, m = self._decode_metrics(z_act, y)
+        return DeviceArray(pred), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
+
+    def getLatent(self, inputs, *, _eps=None):
+        """reference nolbo.py:1557-1566 (VAE: a SAMPLED z) / :1355-1358 (AE: the encoder output) -> numpy [B,L]."""
+        z, _, _ = self._encode_latent(self._dev(inputs), _eps)
+        return np.array(DeviceArray(z))
+
+    def eval_forward_device(self, x, y, eps=None):
+        """Device-resident core of getEval(missing_prob=0) (reference nolbo.py:1463-1501): what bench.py times.
+        x, y: float32 CUDA tensors [B,D,D,D,1]; returns (pred, stats [B,4], metrics [4], kl [B] or None), all on device."""
+        z, z_act, kl = self._encode_latent(x, eps)
+        pred, stats, m = self._decode_metrics(z_act, y)
+        return pred, stats, m, kl
+
+    # ---------------------------------------------------------------- checkpoints (reference nolbo.py:1568-1592)
+    def saveEncoder(self, save_path):
+        file_name = self._enc_str['name']
+        self._encoder.save_weights(os.path.join(save_path, file_name))
+
+    def saveDecoder(self, save_path):
+        file_name = self._dec_str['name']
+        self._decoder.save_weights(os.path.join(save_path, file_name))
+
+    def saveModel(self, save_path):
+        self.saveEncoder(save_path=save_path)
+        self.saveDecoder(save_path=save_path)
+
+    def loadEncoder(self, load_path, file_name=None):
+        if file_name == None:
+            file_name = self._enc_str['name']
+        self._encoder.load_weights(os.path.join(load_path, file_name))
+
+    def loadDecoder(self, load_path, file_name=None):
+        if file_name == None:
+            file_name = self._dec_str['name']
+        self._decoder.load_weights(os.path.join(load_path, file_name))
+
+    def loadModel(self, load_path):
+        self.loadEncoder(load_path=load_path)
+        self.loadDecoder(load_path=load_path)
+
+
+class nolboSingleObject_modelnet_category_AE(_ModelnetBase):
+    """reference nolbo.py:1206-1385."""
+    _variational = False
+
+    def __init__(self, nolbo_structure,
+                 learning_rate=1e-4,
+                 dropout=False):
+        self._enc_backbone_str = nolbo_structure
+        self._enc_str = nolbo_structure['encoder']
+        self._dec_str = nolbo_structure['decoder']
+        self._dropout = dropout
+        self._learning_rate = learning_rate
+        self._buildModel()
+
+    def fit(self, inputs):
+        """reference nolbo.py:1230-1258 -> (loss_shape, pr, rc)."""
+        raise NotImplementedError('training path (BN batch statistics, backward, Adam) is not built yet')
+
+
+class nolboSingleObject_modelnet_category_VAE(_ModelnetBase):
+    """reference nolbo.py:1387-1592."""
+    _variational = True
+
+    def __init__(self, nolbo_structure,
+                 dropout=False,
+                 learning_rate=1e-4):
+        self._enc_backbone_str = nolbo_structure
+        self._enc_str = nolbo_structure['encoder']
+        self._dec_str = nolbo_structure['decoder']
+        self._dropout = dropout
+        self._learning_rate = learning_rate
+        self._buildModel()
+
+    def fit(self, inputs):
+        """reference nolbo.py:1411-1447 -> (loss_kl, loss_shape, pr, rc)."""
+        raise NotImplementedError('training path (BN batch statistics, backward, Adam) is not built yet')

@@ -28,6 +28,31 @@ def _require_gpu():
         raise L.VoxVaeError('no HIP device visible: the voxel VAE path runs on MI355X only (no CPU fallback)')
 
 
+class LayerTimer:
+    """Optional per-layer HIP-event timing on the launch stream (bench.py's roofline leg).  `only` restricts the
+    events to one layer name so the timed region carries two events per step, not two per layer."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.events = {}
+
+    def begin(self, name):
+        if self.only is not None and name != self.only:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return name, e0, e1
+
+    def end(self, tok):
+        if tok is not None:
+            tok[2].record()
+            self.events.setdefault(tok[0], []).append((tok[1], tok[2]))
+
+    def summary_ms(self):
+        """name -> (launches, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
 class _Workspace:
     """Grow-only scratch buffer shared by the layers of one engine (split-K slabs, loss partials)."""
 
@@ -55,6 +80,15 @@ class _EngineBase:
         self.ws = _Workspace(self.device)
         self._dirty = True
         self.act = L.ACT[structure['activation']]
+        self.timer = None         # LayerTimer or None
+        self.tag = ''
+
+    def _call(self, layer, fn, *args):
+        t = self.timer
+        tok = t.begin(self.tag + layer) if t is not None else None
+        L.call(fn, *args)
+        if tok is not None:
+            t.end(tok)
 
     # ---- weights
     def set_params(self, params):
@@ -130,6 +164,8 @@ class EncoderEngine(_EngineBase):
         p, f, st = self.params, self.filters, _stream()
         self.packed = {'scale0': None}
         self.packed['scale0'], self.packed['shift0'] = self._fold('bn0', f[0])
+        self.packed['w0'] = self._empty(f[0], 64)
+        L.call('vv_pack_conv_k4', L.ptr(p['conv0/kernel']), L.ptr(self.packed['w0']), 1, f[0], self.dt, st)
         for i in range(1, len(f) - 1):
             w = self._empty(f[i], 64 * f[i - 1])
             L.call('vv_pack_conv_k4', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), f[i - 1], f[i], self.dt, st)
@@ -148,13 +184,13 @@ class EncoderEngine(_EngineBase):
             raise ValueError('encoder input must be contiguous float32 [B,%d,%d,%d,1], got %s %s' % (D, D, D, tuple(x.shape), x.dtype))
         side = D // 2
         h = self._empty(B, side, side, side, f[0])
-        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(self.params['conv0/kernel']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
+        self._call('E1', 'vv_conv3d_first_fwd', L.ptr(x), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
                L.ptr(h), B, D, f[0], self.act, self.dt, st)
         for i in range(1, len(f) - 1):
             nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt)
             ws = self.ws.get(nb)
             o = self._empty(B, side // 2, side // 2, side // 2, f[i])
-            L.call('vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+            self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
                    L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
             h, side = o, side // 2
         i = len(f) - 1
@@ -162,7 +198,7 @@ class EncoderEngine(_EngineBase):
         nb = L.load().vv_dense_workspace_bytes(B, f[i], K, self.dt)
         ws = self.ws.get(nb)
         out = self._empty(B, f[i], dtype=torch.float32)
-        L.call('vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), None, None, L.ptr(out), B, f[i], K, 0, self.dt, L.VV_F32,
+        self._call('E%d' % (i + 1), 'vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), None, None, L.ptr(out), B, f[i], K, 0, self.dt, L.VV_F32,
                L.ptr(ws), ws.numel(), st)
         return out
 
@@ -229,18 +265,18 @@ class DecoderEngine(_EngineBase):
         lin = S ** 3 * self.ch
         ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, lin, self.L, self.dt))
         t = self._empty(B, lin)
-        L.call('vv_dense_fwd', L.ptr(z_act), L.ptr(pk['wd']), L.ptr(pk['scaled']), L.ptr(pk['shiftd']), L.ptr(t), B, lin,
+        self._call('D0', 'vv_dense_fwd', L.ptr(z_act), L.ptr(pk['wd']), L.ptr(pk['scaled']), L.ptr(pk['shiftd']), L.ptr(t), B, lin,
                self.L, self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
         n0 = S ** 3 * f[0]
         ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, n0, lin, self.dt))
         h = self._empty(B, S, S, S, f[0])
-        L.call('vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
+        self._call('D1', 'vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
                self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
         side = S
         for i in range(1, len(f) - 1):
             ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))
             o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
-            L.call('vv_convT3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+            self._call('D%d' % (i + 1), 'vv_convT3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
                    L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
             h, side = o, 2 * side
         if target is None:
@@ -251,7 +287,7 @@ class DecoderEngine(_EngineBase):
         logits = self._empty(B, D, D, D, 1, dtype=torch.float32) if (want_logits or not self.final_sigmoid) else None
         stats = self._empty(B, 4, dtype=torch.float32)
         ws = self.ws.get(L.load().vv_convT3d_final_bce_workspace_bytes(B, side))
-        L.call('vv_convT3d_final_bce_fwd', L.ptr(h), L.ptr(self.params['convT%d/kernel' % (len(f) - 1)]), L.ptr(target),
+        self._call('D%d' % len(f), 'vv_convT3d_final_bce_fwd', L.ptr(h), L.ptr(self.params['convT%d/kernel' % (len(f) - 1)]), L.ptr(target),
                L.ptr(probs), L.ptr(logits), L.ptr(stats), B, side, f[-2], gamma, epsilon, self.dt, L.ptr(ws), ws.numel(), st)
         return (probs if self.final_sigmoid else logits), logits, stats
 

@@ -6,6 +6,9 @@ module raises.  Nothing here (or anywhere in the package) imports oracle/.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- FIRST: libvoxvae must bind to the HIP runtime torch already loaded (one runtime per
+#                              process; loading /opt/rocm's copy beside torch's leaves ours without a device)
+
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae.so')
 
@@ -19,6 +22,7 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 SIGNATURES = {
     'vv_abi_version': (_i, []),
     'vv_status_string': (ctypes.c_char_p, [_i]),
+    'vv_last_hip_error': (ctypes.c_char_p, []),
     'vv_pack_conv_k4': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_pack_convT_k4s2': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_pack_conv_k4s1_meanpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -36,6 +40,14 @@ SIGNATURES = {
     'vv_convT3d_final_bce_workspace_bytes': (_sz, [_i, _i]),
     'vv_convT3d_final_bce_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
     'vv_shape_metrics': (_i, [_vp, _vp, _i, _vp]),
+    'vv_latent_mask_fill': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    'vv_nearest_category': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    'vv_latent_correct': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'vv_category_accuracy': (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    'vv_binary_loss': (_i, [_vp, _vp, _f, _f, _f, _vp, _i, ctypes.c_long, _vp]),
+    'vv_voxel_precision_recall': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, ctypes.c_long, _vp]),
+    'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
 }
 
 
@@ -63,7 +75,8 @@ def load():
 
 def check(status, what):
     if status != 0:
-        raise VoxVaeError('%s failed: %s (%d)' % (what, load().vv_status_string(status).decode(), status))
+        detail = ' [%s]' % load().vv_last_hip_error().decode() if status == -6 else ''
+        raise VoxVaeError('%s failed: %s (%d)%s' % (what, load().vv_status_string(status).decode(), status, detail))
 
 
 def call(name, *args):

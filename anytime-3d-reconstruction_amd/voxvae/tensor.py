@@ -1,0 +1,56 @@
+"""DeviceArray: what the model API hands back in place of a tf.Tensor.
+
+The reference's callers only ever do `np.array(t)`, `float(t)`, `len(t)` and tuple-unpacking on
+what getEval/fit return (test_modelnet_VAE.py:128-138), so this wrapper offers exactly that over a
+torch CUDA tensor; conversion to host happens (and synchronises) only when asked for."""
+import numpy as np
+import torch
+
+
+class DeviceArray(object):
+    __slots__ = ('t',)
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype('float32') if self.t.dtype in (torch.float32, torch.bfloat16) else np.dtype('int32')
+
+    def torch(self):
+        return self.t
+
+    def numpy(self):
+        t = self.t
+        if t.dtype == torch.bfloat16:
+            t = t.float()
+        return t.detach().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __float__(self):
+        return float(self.numpy().reshape(-1)[0])
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    def __getitem__(self, idx):
+        return DeviceArray(self.t[idx])
+
+    def __repr__(self):
+        return 'DeviceArray(shape=%s, dtype=%s, device=%s)' % (self.shape, self.t.dtype, self.t.device)
+
+
+def as_device_f32(x, device):
+    """numpy / DeviceArray / torch -> contiguous float32 tensor on `device` (host->device copy if needed)."""
+    if isinstance(x, DeviceArray):
+        x = x.t
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(device)

@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- 32^3 voxel reconstructions/sec at batch 256 on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: encoder -> clip|reparam|KL -> decoder -> sigmoid/BCE/TP/FP/FN,
+i.e. getEval(missing_prob=0) (reference nolbo.py:1463-1501), inputs resident in HBM.  Workload = BASELINE.json
+configs[1] (ModelNet40 VAE, 32^3, batch 256, bf16); synthetic voxels + random-init weights (no dataset/weights exist).
+
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32]
+For N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Eval shards the batch dimension: rank r runs its own 256 reconstructions (weak scaling), no data-path collective.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel, HIP events in
+the timed region) and `cpu_baseline` (the fp32 C oracle, rank 0 at N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'anytime-3d-reconstruction_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--voxel', type=int, default=32)
+    ap.add_argument('--latent', type=int, default=64)
+    ap.add_argument('--cpu-samples', type=int, default=16, help='bounded CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-breakdown', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, ep, dp, x, eps, n):
+    """The oracle as the CPU 'port' baseline (the reference's TF-CPU path cannot exist here: no TensorFlow)."""
+    from oracle import c_oracle as co
+    co.build()
+    n = min(n, x.shape[0])
+    co.vae_eval_forward(cfg, ep, dp, x[:1], x[:1], eps[:1])            # warm-up (page in weights, spin up OpenMP)
+    t0 = time.perf_counter()
+    r = co.vae_eval_forward(cfg, ep, dp, x[:n], x[:n], eps[:n])
+    dt = time.perf_counter() - t0
+    return r, {'value': n / dt, 'unit': 'reconstructions/s', 'cores': co.num_threads(), 'kind': 'port',
+               'sample': '%d of the %d synthetic 32^3 samples, one pass, fp32 C oracle (oracle/voxvae_oracle.c, OpenMP), %.1f s'
+                         % (n, x.shape[0], dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = 'cuda:%d' % local
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device(dev))   # RCCL on ROCm
+
+    import voxvae
+    from voxvae import engine as E
+    from voxvae import synthetic as syn
+    from voxvae import workload
+    voxvae.set_default_dtype(a.dtype)
+    voxvae.set_default_device(dev)
+    import src.module.nolbo as nolbo
+
+    cfg = syn.make_config(a.voxel, a.latent, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    model = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    model._encoder.set_weights_dict(ep)
+    model._decoder.set_weights_dict(dp)
+    xh = syn.make_voxels(a.batch, a.voxel, seed=1234 + rank)
+    epsh = syn.make_eps(a.batch, a.latent, seed=7 + rank)
+    x = torch.from_numpy(xh).to(dev)
+    eps = torch.from_numpy(epsh).to(dev)
+
+    def step():
+        return model.eval_forward_device(x, x, eps)
+
+    # ---- parity gate + CPU baseline (rank 0, N == 1 only)
+    cpu, iou_delta, logit_err = None, None, None
+    pred, stats, metrics, kl = step()
+    torch.cuda.synchronize()
+    if rank == 0 and world == 1 and a.cpu_samples > 0:
+        ref, cpu = cpu_baseline(cfg, ep, dp, xh, epsh, a.cpu_samples)
+        n = ref['bce'].shape[0]
+        s = stats[:n].cpu().numpy().astype(np.float64)
+        iou_g = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
+        iou_c = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
+        iou_delta = float(abs(iou_g.mean() - iou_c.mean()))
+        _, z_act, _ = model._encode_latent(x[:n], eps[:n])
+        _, lg, _ = model._dec_eng.forward(z_act, x[:n], want_logits=True)
+        logit_err = float(np.abs(lg.cpu().numpy() - ref['logits']).max())
+
+    # ---- per-layer breakdown (outside the timed region) -> dominant kernel
+    lm = {n: v for n, v, _ in workload.layer_macs(cfg)}
+    dominant, breakdown = 'D4', None
+    if not a.no_breakdown:
+        t = E.LayerTimer()
+        model._enc_eng.timer = model._dec_eng.timer = t
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        breakdown = {k: round(v[1], 4) for k, v in t.summary_ms().items()}
+        dominant = max(breakdown, key=breakdown.get)
+    tm = E.LayerTimer(only=dominant)
+    model._enc_eng.timer = model._dec_eng.timer = tm
+
+    # ---- timed region
+    for _ in range(a.warmup):
+        step()
+    tm.events.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    nl, kms = tm.summary_ms()[dominant]
+
+    if rank == 0:
+        flops = 2.0 * lm[dominant] * a.batch                     # algorithmic (valid-tap) FLOPs of one launch
+        achieved = flops / (kms * 1e-3)
+        fl_rec, fl_dense = workload.flops_per_reconstruction(cfg)
+        out = {
+            'metric': '32^3 voxel reconstructions/sec at batch=256; IoU delta vs reference',
+            'value': world * a.batch * a.steps / el,
+            'unit': 'reconstructions/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * el / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'ModelNet40 VAE getEval(missing_prob=0), %d^3 voxels, latent %d, batch %d per GPU, '
+                                   'encoder+reparam/KL+decoder+BCE/TP/FP/FN (BASELINE.json configs[1])' % (a.voxel, a.latent, a.batch),
+                       'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'parallelism': 'batch-sharded x%d, no collective' % world},
+            'iou_delta': iou_delta, 'max_logit_err_vs_cpu_oracle': logit_err,
+            'whole_path': {'algorithmic_flops_per_reconstruction': fl_rec, 'dense_flops_per_reconstruction': fl_dense,
+                           'achieved_TFLOPs_per_gpu': fl_rec * a.batch * a.steps / el / 1e12,
+                           'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel (%s, layer %s)' % (a.dtype, dominant),
+                         'achieved': achieved / 1e12, 'peak': PEAK[a.dtype] / 1e12, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK[a.dtype], 'traffic': None,
+                         'launch_ms': kms, 'launches_timed': nl, 'algorithmic_flops_per_launch': flops},
+            'layer_ms': breakdown,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

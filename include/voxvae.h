@@ -38,6 +38,8 @@ typedef enum {
 
 int vv_abi_version(void);
 const char *vv_status_string(int status);
+/* hipGetErrorString of the HIP error behind this thread's most recent VV_ERR_LAUNCH. */
+const char *vv_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Weight packing: Keras variable layouts -> the K-contiguous [N][K] panels the MFMA kernels stream.
@@ -66,9 +68,9 @@ int vv_fold_bn(const float *gamma, const float *beta, const float *mean, const f
  * Layers (inference form: conv -> folded BN -> activation).  scale/shift may be NULL (identity). */
 
 /* conv3DEnc with Cin = 1: Conv3D k4 s2 SAME on the occupancy grid + BN + act (autoencoder3D.py:26-39, first
- * loop iteration :84-85).  x [B,D,D,D,1] float32; w_keras [4,4,4,1,Cout] float32 (used as is);
- * y [B,D/2,D/2,D/2,Cout] dtype. */
-int vv_conv3d_first_fwd(const float *x, const float *w_keras, const float *scale, const float *shift, void *y,
+ * loop iteration :84-85) on the same MFMA tile engine, K = the 64 taps gathered from x.  x [B,D,D,D,1] float32;
+ * w_packed = vv_pack_conv_k4(cin = 1) = [Cout][64]; y [B,D/2,D/2,D/2,Cout] dtype. */
+int vv_conv3d_first_fwd(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
                         int batch, int side, int cout, int act, int dtype, void *stream);
 
 /* conv3DEnc, Cin % 64 == 0: Conv3D k4 s2 SAME + BN + act as an implicit GEMM on MFMA
@@ -117,6 +119,38 @@ int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *t
 /* Batch means of nolbo.py:1498-1501: out[0..3] = mean_b bce, mean_b TP/(TP+FP+1e-10), mean_b TP/(TP+FN+1e-10),
  * mean_b TP/max(TP+FP+FN,1) (IoU: not in the reference). */
 int vv_shape_metrics(const float *stats, float *out4, int batch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Missing-modality evaluation (nolbo.py:1472-1518; AE: 1277-1322; Pascal: 877-918).  prototypes = the
+ * category_vectors array [C,L]; mask [B,L] in {0,1} is the np.random.choice draw of nolbo.py:1475, injected. */
+
+/* z_out = z*mask, then where(z_out == 0, mean_c prototypes, z_out)  (nolbo.py:1477-1482). */
+int vv_latent_mask_fill(const float *z, const float *mask, const float *prototypes, int classes, float *z_out,
+                        void *z_act, int act_dtype, int batch, int latent, void *stream);
+/* argmin[b] = first argmin_c sum_j mask_bj (z_bj - P_cj)^2; mask NULL = all ones (nolbo.py:1489-1493, 1505-1506). */
+int vv_nearest_category(const float *z, const float *mask, const float *prototypes, int classes, int *argmin, int batch,
+                        int latent, void *stream);
+/* z_corr = where(mask == 0, P[argmin] + eps2, z)  (nolbo.py:1507-1510; eps2 = the second normal draw, injected). */
+int vv_latent_correct(const float *z, const float *mask, const float *prototypes, const int *argmin, const float *eps2,
+                      float *z_corr, void *z_act, int act_dtype, int batch, int latent, void *stream);
+/* acc[0] = mean_b [argmin_b == argmax_c onehot_bc]  (nolbo.py:1493-1494). */
+int vv_category_accuracy(const int *argmin, const float *onehot, int classes, float *acc, int batch, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stand-alone loss ops with the signatures of src/module/function.py (the fused kernels above are what the
+ * model classes use; these serve callers that compose the ops themselves). */
+
+/* binary_loss(xPred probabilities, xTarget, epsilon, gamma, b_range) -> [B]  (function.py:73-82). */
+int vv_binary_loss(const float *pred, const float *target, float epsilon, float gamma, float b_range, float *out, int batch,
+                   long voxels, void *stream);
+/* voxelPrecisionRecall(xTarget, xPred, prob) -> TP,FP,FN [B]  (function.py:100-115). */
+int vv_voxel_precision_recall(const float *target, const float *pred, float prob, float *tp, float *fp, float *fn, int batch,
+                              long voxels, void *stream);
+/* kl_loss(mean, logVar, mean_target, logVar_target) -> [B]  (function.py:84-98). */
+int vv_kl_loss(const float *mean, const float *logvar, const float *mean_target, const float *logvar_target, float *out,
+               int batch, int latent, void *stream);
+/* sampling(mu, logVar) = mu + sqrt(exp(logVar))*eps, eps injected  (function.py:35-38). */
+int vv_sampling(const float *mu, const float *logvar, const float *eps, float *out, long n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -131,7 +131,9 @@ def test_conv3d_first(L, dtname, B, D):
     ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
     y = torch.empty(B, D // 2, D // 2, D // 2, 64, dtype=tdt, device=DEV)
     xd, wd, scd, shd = _dev(x), _dev(w), _dev(scale), _dev(shift)
-    L.call('vv_conv3d_first_fwd', L.ptr(xd), L.ptr(wd), L.ptr(scd), L.ptr(shd), L.ptr(y), B, D, 64,
+    wp = torch.empty(64, 64, dtype=tdt, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(wd), L.ptr(wp), 1, 64, dt, _st())
+    L.call('vv_conv3d_first_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, D, 64,
            1, dt, _st())
     torch.cuda.synchronize()
     rt = 'f32' if dtname == 'f32' else 'bf16'
@@ -166,7 +168,7 @@ def test_convT3d_final_bce(L, dtname, B, side):
     torch.cuda.synchronize()
     glg = logits.cpu().numpy().astype(np.float64)
     assert np.abs(glg - lg).max() < 2e-5 * max(1.0, np.abs(lg).max())
-    np.testing.assert_allclose(probs.cpu().numpy(), pr, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(probs.cpu().numpy(), pr, rtol=0, atol=1e-5)  # dp <= 0.25 * dlogit
     s = stats.cpu().numpy().astype(np.float64)
     # clip(sigmoid(l)) then log(1-p) (function.py:79-80) is ill-conditioned near p -> 1 (one ulp of p moves a
     # saturated term by percents), so the loss FORMULA is checked on the kernel's own float32 probabilities ...
