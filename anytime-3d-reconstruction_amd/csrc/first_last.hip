@@ -106,6 +106,132 @@ __global__ __launch_bounds__(256) void final_bce_kernel(const T *__restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// final_bce on MFMA (bf16 activations), scatter form.  A transposed conv with one output channel is
+//   P[i][t] = sum_ci x[i][ci] * w[t][ci]      (a [voxels x 64] x [64 x 64 taps] GEMM: v_mfma_f32_32x32x16_bf16)
+//   logit[o] = sum_{(i,t) : o = 2i + t - 1} P[i][t]   (8 terms per output voxel)
+// One workgroup = 4x4x4 input cells (+1 halo: 216 rows, padded to 224) -> P in LDS (f32, aliased over the
+// staged operands) -> every lane gathers its 2 x 8 terms, then sigmoid / BCE / TP / FP / FN as in the VALU kernel.
+constexpr int FM_ROWS = 224;            // 216 halo voxels padded to 7 MFMA row tiles
+constexpr int FM_PPITCH = 65;           // floats per P row (64 taps + 1: consecutive voxels on consecutive banks)
+
+__device__ __forceinline__ int fm_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ target, float *__restrict__ probs,
+                                                             float *__restrict__ logits, float *__restrict__ partials,
+                                                             int din_log2, float gamma, float epsilon) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *As = smem;                                   // [224][128 B] bf16 rows, slot-swizzled
+    char *Ws = smem + FM_ROWS * 128;                   // [64 taps][128 B]
+    float *P = reinterpret_cast<float *>(smem);        // [216][65] f32, written after the MFMAs (aliases As/Ws)
+    __shared__ float red[4][4];
+    const int li = din_log2, n = 1 << li, nb = n >> 2;
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const int bw = blk % nb, bh = (blk / nb) % nb, bd = blk / (nb * nb);
+    const int m0d = bd * 4, m0h = bh * 4, m0w = bw * 4;
+    const char *xb = reinterpret_cast<const char *>(x + ((size_t)b << (3 * li)) * FB_CIN);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // stage: 224 rows x 8 slots of 16 B
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const int idx = tid + 256 * it, row = idx >> 3, slot = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < 216) {
+            const int zw = row % 6, zh = (row / 6) % 6, zd = row / 36;
+            const int id = m0d - 1 + zd, ih = m0h - 1 + zh, iw = m0w - 1 + zw;
+            if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
+                v = *reinterpret_cast<const uint4 *>(xb + (((((size_t)id << li) + ih) << li) + iw) * (FB_CIN * 2) + slot * 16);
+        }
+        *reinterpret_cast<uint4 *>(As + fm_lds_off(row, slot)) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + 256 * it, row = idx >> 3, slot = idx & 7;
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + row * FB_CIN + slot * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(w + row * FB_CIN + slot * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = static_cast<__bf16>(w0[e]); o[4 + e] = static_cast<__bf16>(w1[e]); }
+        *reinterpret_cast<bf16x8 *>(Ws + fm_lds_off(row, slot)) = o;
+    }
+    __syncthreads();
+
+    // MFMA: wave -> tap tile nt = wv & 1, row tiles mt = (wv >> 1) + 2 j
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nt = wv & 1, mt0 = wv >> 1;
+    uint4 fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const uint4 *>(Ws + fm_lds_off(nt * 32 + fr, ks * 2 + fh));
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        const int mt = mt0 + 2 * j;
+        if (mt < 7) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 fa = *reinterpret_cast<const uint4 *>(As + fm_lds_off(mt * 32 + fr, ks * 2 + fh));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fa),
+                                                                 *reinterpret_cast<const bf16x8 *>(&fb[ks]), acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // every wave is done reading As/Ws: P may overwrite them
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int mt = mt0 + 2 * j;
+        if (mt < 7) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                if (row < 216) P[row * FM_PPITCH + nt * 32 + fr] = acc[j][q];
+            }
+        }
+    }
+    __syncthreads();
+
+    // gather: wave -> output parity (pd, ph); lane -> cell; both pw parities per lane
+    const int pd = wv >> 1, ph = wv & 1;
+    const int mw = lane & 3, mh = (lane >> 2) & 3, md = lane >> 4;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int ad = 0; ad < 2; ++ad) {
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {
+            const int zd = md + pd - ad + 1, zh = mh + ph - ah + 1;
+            const int td = 1 - pd + 2 * ad, th = 1 - ph + 2 * ah;
+            const float *r = P + ((zd * 6 + zh) * 6 + mw) * FM_PPITCH + (td * 4 + th) * 4;
+            acc0 += r[FM_PPITCH + 1] + r[3];                    // pw = 0: i = mw (tw 1), mw-1 (tw 3)
+            acc1 += r[2 * FM_PPITCH + 0] + r[FM_PPITCH + 2];    // pw = 1: i = mw+1 (tw 0), mw (tw 2)
+        }
+    }
+    const int lo = li + 1;
+    const int od = 2 * (m0d + md) + pd, oh = 2 * (m0h + mh) + ph, ow = 2 * (m0w + mw);
+    const size_t o = (((((size_t)b << lo) + od) << lo) + oh << lo) + ow;
+    const float2 y = *reinterpret_cast<const float2 *>(target + o);
+    const float l[2] = {acc0, acc1}, yy[2] = {y.x, y.y};
+    float p[2], bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    const float hi = 1.0f - epsilon;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        p[e] = 1.0f / (1.0f + expf(-l[e]));
+        const float q = fminf(fmaxf(p[e], epsilon), hi);
+        bce -= gamma * yy[e] * logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * logf(1.0f - q);
+        const float yh = p[e] >= 0.5f ? 1.f : 0.f;
+        tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
+    }
+    if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+    if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+    bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
+    if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
+    __syncthreads();
+    if (tid < 4) partials[((size_t)b * gridDim.x + blk) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nblk) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -139,8 +265,8 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *partials = reinterpret_cast<float *>(workspace);
     if (dtype == VV_BF16)
-        VV_LAUNCH((final_bce_kernel<__bf16>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x),
-                           w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
+        VV_LAUNCH(final_bce_mfma_kernel, dim3(nblk, batch), dim3(256), (size_t)216 * FM_PPITCH * 4, st,
+                  reinterpret_cast<const __bf16 *>(x), w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
     else
         VV_LAUNCH((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);

@@ -129,16 +129,25 @@ __device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, 
     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc, 0, 0, 0);
 }
 
+// 128 zero bytes in global memory: the LDS-DMA source of every row that falls in the SAME padding, past M/N or
+// past a dense K tail (an LDS-DMA lane cannot be predicated off without leaving stale bytes in its LDS slot).
+__device__ __attribute__((aligned(128))) unsigned int vv_zero_page[32];
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
 template <typename T, int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int BK = Elt<T>::BK;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 tiles per wave (waves laid out 2 x 2)
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
+    constexpr bool DMA = MODE != MODE_FIRST;   // global -> LDS directly (global_load_lds_dwordx4), no VGPR round trip
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *As = smem;                       // [2][BM][128]
     char *Bs = smem + 2 * BM * ROWB;       // [2][BN][128]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (a.N + BN - 1) / BN;
     const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
@@ -147,21 +156,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int kc_begin = split * a.chunks_per_split;
     const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
 
-    const int chunk = tid & 7, r0 = tid >> 3;
+    // Lane -> (row r0 + 32 i, 16-byte slot `pos`) of the staged images.  The LDS image is written linearly (slot pos
+    // of row r at r*128 + pos*16, as LDS-DMA requires); the XOR swizzle is applied on the SOURCE side: the lane
+    // fetches global slot gchunk = pos ^ f(row), f(row) = (row >> 1) & 7, and fragment reads look a slot c up at
+    // position c ^ f(row).  f is the same for rows r0 + 32 i.
+    const int pos = tid & 7, r0 = tid >> 3;
+    const int gchunk = pos ^ ((r0 >> 1) & 7);
     const char *Ab = reinterpret_cast<const char *>(a.A);
     const char *Wb = reinterpret_cast<const char *>(a.W) + (size_t)parity * a.N * a.K * sizeof(T);
+    const char *zero = reinterpret_cast<const char *>(vv_zero_page) + pos * 16;
 
     RowCtx rows[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) rows[i] = make_row<MODE>(a, m0 + r0 + 32 * i, parity);
     size_t wrow[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) wrow[i] = (size_t)(n0 + r0 + 32 * i) * a.K * sizeof(T) + chunk * 16;
+    for (int i = 0; i < RB; ++i) wrow[i] = (size_t)(n0 + r0 + 32 * i) * a.K * sizeof(T) + gchunk * 16;
+    const bool ktail_ok = true;
+    (void)ktail_ok;
 
-    uint4 ra[RA], rb[RB];
+    // ---- DMA path: one global_load_lds_dwordx4 per staged row per thread; a wave instruction fills 8 rows (1 KiB)
+    auto issue = [&](int kc, int buf) {
+        const bool kin = (MODE != MODE_DENSE) || (kc * BK + gchunk * (BK / 8) < a.K);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int off;
+            const bool v = row_chunk<MODE, BK>(a, rows[i], kc, gchunk, off);
+            const char *src = v ? Ab + (long)off * (long)sizeof(T) + gchunk * 16 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const char *src = (n0 + r0 + 32 * i < a.N && kin) ? Wb + wrow[i] + (size_t)kc * ROWB : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB), 16, 0, 0);
+        }
+    };
+
+    // ---- register path (MODE_FIRST): slot gchunk of K chunk kc holds 16/sizeof(T) consecutive taps
+    // t = (td*4 + th)*4 + tw of the 4x4x4 window, gathered from the float32 grid and converted
+    uint4 ra[DMA ? 1 : RA], rb[DMA ? 1 : RB];
     auto gload = [&](int kc) {
-        if constexpr (MODE == MODE_FIRST) {
-            // slot `chunk` of K chunk kc holds 16/sizeof(T) consecutive taps t = (td*4 + th)*4 + tw of the window
+        if constexpr (!DMA) {
             constexpr int EPS = 16 / (int)sizeof(T);
             const int n = 1 << a.din_log2;
             const float *xf = reinterpret_cast<const float *>(a.A);
@@ -170,33 +205,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 T vals[EPS];
 #pragma unroll
                 for (int e = 0; e < EPS; ++e) {
-                    const int t = kc * BK + chunk * EPS + e;
+                    const int t = kc * BK + gchunk * EPS + e;
                     const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
                     const bool ok = rows[i].ok && (unsigned)(rows[i].d0 + td) < (unsigned)n &&
                                     (unsigned)(rows[i].h0 + th) < (unsigned)n && (unsigned)(rows[i].w0 + tw) < (unsigned)n;
-                    const float v = ok ? xf[rows[i].off0 + ((td << a.din_log2) + th << a.din_log2) + tw] : 0.f;
+                    const float v = ok ? xf[rows[i].off0 + ((((td << a.din_log2) + th) << a.din_log2) + tw)] : 0.f;
                     vals[e] = static_cast<T>(v);
                 }
                 ra[i] = *reinterpret_cast<const uint4 *>(vals);
             }
-        } else {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            int off;
-            const bool v = row_chunk<MODE, BK>(a, rows[i], kc, chunk, off);
-            ra[i] = v ? *reinterpret_cast<const uint4 *>(Ab + (long)off * (long)sizeof(T) + chunk * 16) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < RB; ++i)
+                rb[i] = (n0 + r0 + 32 * i < a.N) ? *reinterpret_cast<const uint4 *>(Wb + wrow[i] + (size_t)kc * ROWB)
+                                                 : make_uint4(0, 0, 0, 0);
         }
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            rb[i] = (n0 + r0 + 32 * i < a.N && (MODE != MODE_DENSE || kc * BK + chunk * (BK / 8) < a.K))
-                        ? *reinterpret_cast<const uint4 *>(Wb + wrow[i] + (size_t)kc * ROWB) : make_uint4(0, 0, 0, 0);
     };
     auto lstore = [&](int buf) {
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4 *>(As + buf * BM * ROWB + lds_off(r0 + 32 * i, chunk)) = ra[i];
+            for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4 *>(As + buf * BM * ROWB + (r0 + 32 * i) * ROWB + pos * 16) = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(Bs + buf * BN * ROWB + lds_off(r0 + 32 * i, chunk)) = rb[i];
+            for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4 *>(Bs + buf * BN * ROWB + (r0 + 32 * i) * ROWB + pos * 16) = rb[i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -209,14 +239,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const int fr = lane & 31, fh = lane >> 5;
     if (kc_begin < kc_end) {
-        gload(kc_begin);
-        lstore(0);
+        if constexpr (DMA) issue(kc_begin, 0);
+        else { gload(kc_begin); lstore(0); }
     }
-    __syncthreads();
+    __syncthreads();  // (the compiler drains vmcnt before the barrier while an LDS-DMA is outstanding)
     int buf = 0;
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const bool more = kc + 1 < kc_end;
-        if (more) gload(kc + 1);
+        if (more) {
+            if constexpr (DMA) issue(kc + 1, buf ^ 1);
+            else gload(kc + 1);
+        }
         const char *Ac = As + buf * BM * ROWB, *Bc = Bs + buf * BN * ROWB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -237,13 +270,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         buf ^= 1;
     }
 
-    // epilogue: lane owns column n, registers walk rows (32x32 C/D map: row = (q&3) + 8*(q>>2) + 4*h)
+    // ---- epilogue.  Accumulators (lane = column n, registers walk rows: row = (q&3) + 8*(q>>2) + 4*h) get the folded
+    // BN + activation, are transposed through LDS into [BM][BN] row-major tiles of the OUTPUT element type, and leave as
+    // 16-byte stores: whole channel rows, coalesced.  Split-K writes raw f32 slabs the same way.
+    const bool to_f32 = a.partial != nullptr || !a.out_bf16;
+    const int es = to_f32 ? 4 : 2;
+    const int pitch = BN * es + 16;   // +16 B: rows 4 apart (the two lane halves of one store) land on different banks
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + fr;
-        if (n >= a.N) continue;
+        const int cl = wn * (BN / 2) + j * 32 + fr;
+        const int n = n0 + cl;
         float sc = 1.f, sh = 0.f;
-        if (!a.partial) {
+        if (!a.partial && n < a.N) {
             if (a.scale) sc = a.scale[n];
             if (a.shift) sh = a.shift[n];
         }
@@ -251,18 +289,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-                if (m >= a.M) continue;
-                if (a.partial) {
-                    a.partial[((size_t)(split * gridDim.z + parity) * a.M + m) * a.N + n] = acc[i][j][q];
-                } else {
-                    const float v = vv_apply_act(acc[i][j][q] * sc + sh, a.act);
-                    const size_t o = out_row<MODE>(a, m, parity) + n;
-                    if (a.out_bf16) reinterpret_cast<__bf16 *>(a.Out)[o] = static_cast<__bf16>(v);
-                    else reinterpret_cast<float *>(a.Out)[o] = v;
-                }
+                const int rl = wm * (BM / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                const float v = a.partial ? acc[i][j][q] : vv_apply_act(acc[i][j][q] * sc + sh, a.act);
+                if (to_f32) *reinterpret_cast<float *>(smem + rl * pitch + cl * 4) = v;
+                else *reinterpret_cast<__bf16 *>(smem + rl * pitch + cl * 2) = static_cast<__bf16>(v);
             }
         }
+    }
+    __syncthreads();
+    const int cpr = BN * es / 16;  // 16-byte chunks per tile row
+    char *outb = a.partial ? reinterpret_cast<char *>(a.partial) : reinterpret_cast<char *>(a.Out);
+    const int epc = 16 / es;
+    for (int idx = tid; idx < BM * cpr; idx += 256) {
+        const int rl = idx / cpr, c = idx % cpr;
+        const int m = m0 + rl, n = n0 + c * epc;
+        if (m >= a.M || n >= a.N) continue;
+        const size_t row = a.partial ? ((size_t)(split * gridDim.z + parity) * a.M + m) * a.N : out_row<MODE>(a, m, parity);
+        *reinterpret_cast<uint4 *>(outb + (row + n) * es) = *reinterpret_cast<const uint4 *>(smem + rl * pitch + c * 16);
     }
 }
 
@@ -315,10 +358,12 @@ template <typename T, int MODE>
 int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     const int tiles = ((a.M + p.bm - 1) / p.bm) * ((a.N + p.bn - 1) / p.bn);
     dim3 grid(tiles, p.split, p.nparity);
-    const size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB;
+    size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB;
+    const size_t lds_epi = (size_t)p.bm * (p.bn * 4 + 16);
+    if (lds_epi > lds) lds = lds_epi;
     static const bool attr_set = [] {  // 64 KiB of dynamic LDS for the 128x128 tile
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * ROWB);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
         return true;
     }();
     (void)attr_set;
@@ -338,7 +383,7 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (out_dtype != VV_F32 && out_dtype != VV_BF16) return VV_ERR_DTYPE;
     const int bk = dtype == VV_BF16 ? 64 : 32;
-    if (M <= 0 || N <= 0 || K <= 0 || N % 4) return VV_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || N % (out_dtype == VV_BF16 ? 8 : 4)) return VV_ERR_SHAPE;
     if (mode == MODE_DENSE ? (K % (bk / 8)) != 0 : (K % bk) != 0) return VV_ERR_SHAPE;
     if (mode == MODE_FIRST && (!vv_is_pow2(din) || cin != 1)) return VV_ERR_SHAPE;
     if ((mode == MODE_CONV || mode == MODE_CONVT) && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;

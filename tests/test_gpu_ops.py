@@ -150,7 +150,7 @@ def test_convT3d_final_bce(L, dtname, B, side):
     x = rng.standard_normal((B, side, side, side, 64)).astype(np.float32)
     w = (rng.standard_normal((4, 4, 4, 1, 64)) * 0.3).astype(np.float32)
     if dtname == 'bf16':
-        x = _bf16_round(x)
+        x, w = _bf16_round(x), _bf16_round(w)   # the bf16 path feeds MFMA: both operands are bf16
     D = 2 * side
     y = (rng.random((B, D, D, D, 1)) < 0.3).astype(np.float32)
     lg = no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2)
