@@ -45,6 +45,16 @@ __device__ __forceinline__ float vv_apply_act(float v, int act) {
     }
 }
 
+// Same, for values about to be rounded to bf16 (8 significant bits): exp through v_exp_f32 instead of expm1f.
+__device__ __forceinline__ float vv_apply_act_fast(float v, int act) {
+    switch (act) {
+        case VV_ACT_ELU: return v > 0.f ? v : __expf(v) - 1.f;
+        case VV_ACT_RELU: return v > 0.f ? v : 0.f;
+        case VV_ACT_LRELU: return v > 0.f ? v : 0.3f * v;
+        default: return v;
+    }
+}
+
 __device__ __forceinline__ float vv_load_f32(const float *p, size_t i) { return p[i]; }
 __device__ __forceinline__ float vv_load_f32(const __bf16 *p, size_t i) { return static_cast<float>(p[i]); }
 __device__ __forceinline__ void vv_store(float *p, size_t i, float v) { p[i] = v; }

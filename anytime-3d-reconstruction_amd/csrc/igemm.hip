@@ -16,6 +16,8 @@
 // v_mfma_f32_32x32x2_f32 (exact-f32 parity mode).  One 256-thread workgroup (4 waves, 2x2) owns a BM x BN tile;
 // global loads of chunk k+1 are in flight while chunk k is multiplied (register prefetch + LDS double buffer).
 // Split-K writes f32 slabs that igemm_splitk_epilogue sums in a fixed order (deterministic).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -37,6 +39,10 @@ struct IgemmArgs {
     int chunks_per_split;
     int act;
     int out_bf16;      // output element type (1 bf16, 0 f32)
+    int batch;         // samples (conv modes)
+    unsigned a_bytes, w_bytes;  // operand sizes for the buffer descriptors (out-of-range lanes read zeros)
+    int nsplit, nparity;  // split-K shares and output-parity panels (both folded into the 1-D grid)
+    int pos_major;     // conv modes: GEMM row m = position * batch + sample (tiles share a position -> padded taps skipped)
 };
 
 constexpr int ROWB = 128;  // bytes per staged row = one K chunk
@@ -54,6 +60,14 @@ struct RowCtx {
     bool ok;
 };
 
+// GEMM row -> (sample, position-in-grid).  Sample-major: rows of one sample are contiguous (L1 reuse across taps);
+// position-major: rows of one output position are contiguous, so a tile sees ONE position and every tap that falls
+// into the SAME padding for it is skipped for the whole tile (58 % of the taps of a 4^3 -> 2^3 layer).
+__device__ __forceinline__ void split_row(const IgemmArgs &a, int m, int pos_log2, int &b, int &pos) {
+    if (a.pos_major) { pos = m / a.batch; b = m - pos * a.batch; }
+    else { b = m >> pos_log2; pos = m & ((1 << pos_log2) - 1); }
+}
+
 template <int MODE>
 __device__ __forceinline__ RowCtx make_row(const IgemmArgs &a, int m, int parity) {
     RowCtx r;
@@ -65,15 +79,16 @@ __device__ __forceinline__ RowCtx make_row(const IgemmArgs &a, int m, int parity
     }
     const int li = a.din_log2, n = 1 << li;
     int b;
+    int pos;
     if (MODE == MODE_CONV || MODE == MODE_FIRST) {
         const int lo = li - 1, msk = (1 << lo) - 1;
-        const int ow = m & msk, oh = (m >> lo) & msk, od = (m >> (2 * lo)) & msk;
-        b = m >> (3 * lo);
+        split_row(a, m, 3 * lo, b, pos);
+        const int ow = pos & msk, oh = (pos >> lo) & msk, od = (pos >> (2 * lo)) & msk;
         r.d0 = 2 * od - 1; r.h0 = 2 * oh - 1; r.w0 = 2 * ow - 1;  // SAME, k4 s2: pad_before = 1
     } else {
         const int msk = n - 1;
-        const int mw = m & msk, mh = (m >> li) & msk, md = (m >> (2 * li)) & msk;
-        b = m >> (3 * li);
+        split_row(a, m, 3 * li, b, pos);
+        const int mw = pos & msk, mh = (pos >> li) & msk, md = (pos >> (2 * li)) & msk;
         r.d0 = md + ((parity >> 2) & 1); r.h0 = mh + ((parity >> 1) & 1); r.w0 = mw + (parity & 1);
     }
     r.off0 = (((b * n + r.d0) * n + r.h0) * n + r.w0) * a.cin;  // may be out of range for padded taps: never dereferenced
@@ -105,11 +120,41 @@ __device__ __forceinline__ bool row_chunk(const IgemmArgs &a, const RowCtx &r, i
 // output element offset of row m (channel 0)
 template <int MODE>
 __device__ __forceinline__ size_t out_row(const IgemmArgs &a, int m, int parity) {
-    if (MODE != MODE_CONVT) return (size_t)m * a.N;
-    const int li = a.din_log2, msk = (1 << li) - 1, lo = li + 1;
-    const int mw = m & msk, mh = (m >> li) & msk, md = (m >> (2 * li)) & msk, b = m >> (3 * li);
+    if (MODE == MODE_DENSE) return (size_t)m * a.N;
+    const int li = a.din_log2;
+    int b, pos;
+    if (MODE != MODE_CONVT) {
+        const int lo3 = 3 * (li - 1);
+        split_row(a, m, lo3, b, pos);
+        return (((size_t)b << lo3) + pos) * a.N;
+    }
+    const int msk = (1 << li) - 1, lo = li + 1;
+    split_row(a, m, 3 * li, b, pos);
+    const int mw = pos & msk, mh = (pos >> li) & msk, md = (pos >> (2 * li)) & msk;
     const size_t od = 2 * md + ((parity >> 2) & 1), oh = 2 * mh + ((parity >> 1) & 1), ow = 2 * mw + (parity & 1);
     return (((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow) * (size_t)a.N;
+}
+
+// bit t set <=> tap t touches real data for this row (conv: t = (td*4+th)*4+tw; transposed: t = (ad*2+ah)*2+aw)
+template <int MODE>
+__device__ __forceinline__ unsigned long long row_tapmask(const IgemmArgs &a, const RowCtx &r) {
+    if (!r.ok) return 0ull;
+    const int n = 1 << a.din_log2;
+    unsigned long long m = 0ull;
+    if (MODE == MODE_CONV) {
+        unsigned vw = 0;
+        for (int t = 0; t < 4; ++t) vw |= ((unsigned)(r.w0 + t) < (unsigned)n) << t;
+        for (int td = 0; td < 4; ++td)
+            for (int th = 0; th < 4; ++th)
+                if ((unsigned)(r.d0 + td) < (unsigned)n && (unsigned)(r.h0 + th) < (unsigned)n)
+                    m |= (unsigned long long)vw << ((td * 4 + th) * 4);
+    } else {
+        for (int t = 0; t < 8; ++t)
+            if ((unsigned)(r.d0 - (t >> 2)) < (unsigned)n && (unsigned)(r.h0 - ((t >> 1) & 1)) < (unsigned)n &&
+                (unsigned)(r.w0 - (t & 1)) < (unsigned)n)
+                m |= 1ull << t;
+    }
+    return m;
 }
 
 template <typename T>
@@ -129,11 +174,6 @@ __device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, 
     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc, 0, 0, 0);
 }
 
-// 128 zero bytes in global memory: the LDS-DMA source of every row that falls in the SAME padding, past M/N or
-// past a dense K tail (an LDS-DMA lane cannot be predicated off without leaving stale bytes in its LDS slot).
-__device__ __attribute__((aligned(128))) unsigned int vv_zero_page[32];
-
-typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 template <typename T, int MODE, int BM, int BN>
@@ -149,9 +189,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so block b
+    // takes item (b % 8) * (T / 8) + b / 8 of a list ordered parity -> split -> n tile -> m tile (fastest first):
+    // every XCD walks a contiguous stretch of the list, and the 8 parity panels (or the split-K shares) of one tile,
+    // then the neighbouring tiles of the same sample, run on ONE XCD back to back and share their input rows in its L2.
     const int ntn = (a.N + BN - 1) / BN;
-    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
-    const int split = blockIdx.y, parity = blockIdx.z;
+    const int nwg = gridDim.x;
+    const int wi = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+    const int parity = wi % a.nparity;
+    const int split = (wi / a.nparity) % a.nsplit;
+    const int tl = wi / (a.nparity * a.nsplit);
+    const int tile_n = tl % ntn, tile_m = tl / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kc_begin = split * a.chunks_per_split;
     const int kc_end = min(a.nchunks, kc_begin + a.chunks_per_split);
@@ -164,31 +212,86 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int gchunk = pos ^ ((r0 >> 1) & 7);
     const char *Ab = reinterpret_cast<const char *>(a.A);
     const char *Wb = reinterpret_cast<const char *>(a.W) + (size_t)parity * a.N * a.K * sizeof(T);
-    const char *zero = reinterpret_cast<const char *>(vv_zero_page) + pos * 16;
 
     RowCtx rows[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) rows[i] = make_row<MODE>(a, m0 + r0 + 32 * i, parity);
-    size_t wrow[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) wrow[i] = (size_t)(n0 + r0 + 32 * i) * a.K * sizeof(T) + gchunk * 16;
-    const bool ktail_ok = true;
-    (void)ktail_ok;
 
-    // ---- DMA path: one global_load_lds_dwordx4 per staged row per thread; a wave instruction fills 8 rows (1 KiB)
-    auto issue = [&](int kc, int buf) {
+    constexpr bool TAPS = MODE == MODE_CONV || MODE == MODE_CONVT;
+    // Everything per-row that the K loop needs is hoisted here: a 64-bit source base (tap 0, channel 0, this lane's
+    // slot), a per-tap validity bitmask, and for the weights a base + validity.  The loop then adds one wave-uniform
+    // delta per chunk and selects the zero page for padded taps: ~7 VALU per staged row instead of a coordinate decode.
+    // LDS-DMA goes through buffer descriptors: a lane whose offset is out of range deposits ZEROS in its LDS slot, which
+    // is exactly what a tap in the SAME padding (or a row past M / N / K) must contribute -- no zero page, no branches.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.A), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.W), 0, a.w_bytes, 0x00020000);
+    int aoff[RA];                     // byte offset of (row, tap 0, channel 0, this lane's slot); garbage where never valid
+    unsigned long long rmask[RA];     // per-tap validity of the row
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        aoff[i] = rows[i].off0 * (int)sizeof(T) + gchunk * 16;
+        rmask[i] = TAPS ? row_tapmask<MODE>(a, rows[i]) : (rows[i].ok ? ~0ull : 0ull);
+    }
+    unsigned woff[RB];                // byte offset of (weight row, k 0, this lane's slot); OOB past N
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        woff[i] = (n0 + r0 + 32 * i < a.N) ? (unsigned)(((size_t)parity * a.N + n0 + r0 + 32 * i) * a.K * sizeof(T)) + gchunk * 16 : OOB;
+    const char *wbase_reg[1] = {Wb};  // (register path below indexes weights through woff as well)
+    (void)wbase_reg;
+
+    // Tile-uniform list of taps that touch real data for at least one row (smem tail, lives through the K loop).
+    int *taplist = reinterpret_cast<int *>(smem + 2 * (BM + BN) * ROWB);   // [64] + 2 mask words
+    int nvalid = kc_end - kc_begin, vb = kc_begin;                         // dense / first: chunks are the list
+    if constexpr (TAPS) {
+        unsigned *mw = reinterpret_cast<unsigned *>(taplist + 64);
+        if (tid < 2) mw[tid] = 0u;
+        __syncthreads();
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) mine |= rmask[i];
+        if ((unsigned)mine) atomicOr(&mw[0], (unsigned)mine);
+        if ((unsigned)(mine >> 32)) atomicOr(&mw[1], (unsigned)(mine >> 32));
+        __syncthreads();
+        const unsigned long long tapmask = ((unsigned long long)mw[1] << 32) | mw[0];
+        if (tid < 64 && ((tapmask >> tid) & 1ull)) taplist[__builtin_popcountll(tapmask & ((1ull << tid) - 1ull))] = tid;
+        __syncthreads();
+        const int ntap = __builtin_amdgcn_readfirstlane(__builtin_popcountll(tapmask));
+        const int total = ntap << a.cpt_log2;                 // valid chunks of this tile
+        const int per = (total + a.nsplit - 1) / a.nsplit;   // split-K shares cut from the VALID list
+        vb = split * per;
+        nvalid = max(0, min(total, vb + per) - vb);
+    }
+
+    // ---- DMA path: one buffer_load_dwordx4 ... lds per staged row per thread; a wave instruction fills 8 rows (1 KiB).
+    // Per chunk and row: test one bit, add the wave-uniform tap delta, select OOB.  Weights: the delta rides in soffset.
+    auto issue = [&](int vi, int buf) {
+        int tap = 0, kc = vi, delta;
+        if constexpr (TAPS) {
+            const int sub = vi & ((1 << a.cpt_log2) - 1);
+            tap = __builtin_amdgcn_readfirstlane(taplist[vi >> a.cpt_log2]);
+            kc = (tap << a.cpt_log2) + sub;
+            const int li = a.din_log2;
+            int toff;
+            if (MODE == MODE_CONV) toff = ((((tap >> 4) << li) + ((tap >> 2) & 3)) << li) + (tap & 3);
+            else toff = -(((((tap >> 2) << li) + ((tap >> 1) & 1)) << li) + (tap & 1));
+            delta = (toff * a.cin + sub * BK) * (int)sizeof(T);
+        } else {
+            delta = kc * ROWB;
+        }
         const bool kin = (MODE != MODE_DENSE) || (kc * BK + gchunk * (BK / 8) < a.K);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            int off;
-            const bool v = row_chunk<MODE, BK>(a, rows[i], kc, gchunk, off);
-            const char *src = v ? Ab + (long)off * (long)sizeof(T) + gchunk * 16 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB), 16, 0, 0);
+            bool v;
+            if constexpr (MODE == MODE_CONV) v = (rmask[i] >> tap) & 1ull;
+            else v = ((unsigned)rmask[i] >> tap) & 1u;
+            const unsigned vo = (v && kin) ? (unsigned)(aoff[i] + delta) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const char *src = (n0 + r0 + 32 * i < a.N && kin) ? Wb + wrow[i] + (size_t)kc * ROWB : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB), 16, 0, 0);
+            const unsigned vo = kin ? woff[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB), 16, vo, kc * ROWB, 0, 0);
         }
     };
 
@@ -216,8 +319,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
-                rb[i] = (n0 + r0 + 32 * i < a.N) ? *reinterpret_cast<const uint4 *>(Wb + wrow[i] + (size_t)kc * ROWB)
-                                                 : make_uint4(0, 0, 0, 0);
+                rb[i] = woff[i] != OOB ? *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.W) + woff[i] + (size_t)kc * ROWB)
+                                       : make_uint4(0, 0, 0, 0);
         }
     };
     auto lstore = [&](int buf) {
@@ -238,17 +341,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
-    if (kc_begin < kc_end) {
-        if constexpr (DMA) issue(kc_begin, 0);
-        else { gload(kc_begin); lstore(0); }
+    int vi = vb;
+    const int ve = vb + nvalid;
+    if (vi < ve) {
+        if constexpr (DMA) issue(vi, 0);
+        else { gload(vi); lstore(0); }
     }
     __syncthreads();  // (the compiler drains vmcnt before the barrier while an LDS-DMA is outstanding)
     int buf = 0;
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-        const bool more = kc + 1 < kc_end;
+    for (; vi < ve; ++vi) {
+        const bool more = vi + 1 < ve;
         if (more) {
-            if constexpr (DMA) issue(kc + 1, buf ^ 1);
-            else gload(kc + 1);
+            if constexpr (DMA) issue(vi + 1, buf ^ 1);
+            else gload(vi + 1);
         }
         const char *Ac = As + buf * BM * ROWB, *Bc = Bs + buf * BN * ROWB;
 #pragma unroll
@@ -290,7 +395,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int rl = wm * (BM / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-                const float v = a.partial ? acc[i][j][q] : vv_apply_act(acc[i][j][q] * sc + sh, a.act);
+                const float v = a.partial ? acc[i][j][q]
+                                          : (to_f32 ? vv_apply_act(acc[i][j][q] * sc + sh, a.act) : vv_apply_act_fast(acc[i][j][q] * sc + sh, a.act));
                 if (to_f32) *reinterpret_cast<float *>(smem + rl * pitch + cl * 4) = v;
                 else *reinterpret_cast<__bf16 *>(smem + rl * pitch + cl * 2) = static_cast<__bf16>(v);
             }
@@ -304,7 +410,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const int rl = idx / cpr, c = idx % cpr;
         const int m = m0 + rl, n = n0 + c * epc;
         if (m >= a.M || n >= a.N) continue;
-        const size_t row = a.partial ? ((size_t)(split * gridDim.z + parity) * a.M + m) * a.N : out_row<MODE>(a, m, parity);
+        const size_t row = a.partial ? ((size_t)(split * a.nparity + parity) * a.M + m) * a.N : out_row<MODE>(a, m, parity);
         *reinterpret_cast<uint4 *>(outb + (row + n) * es) = *reinterpret_cast<const uint4 *>(smem + rl * pitch + c * 16);
     }
 }
@@ -354,16 +460,26 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     return p;
 }
 
+// Position-major rows pay off where a large share of the taps is padding (small grids) and the batch fills tiles.
+bool use_pos_major(int mode, int din, int batch) {
+    static const int conv_max = getenv("VV_POSMAJOR_CONV_SIDE") ? atoi(getenv("VV_POSMAJOR_CONV_SIDE")) : 8;
+    static const int convT_max = getenv("VV_POSMAJOR_CONVT_SIDE") ? atoi(getenv("VV_POSMAJOR_CONVT_SIDE")) : 4;
+    if (batch < 32) return false;
+    if (mode == MODE_CONV) return din <= conv_max;
+    if (mode == MODE_CONVT) return din <= convT_max;
+    return false;
+}
+
 template <typename T, int MODE>
 int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     const int tiles = ((a.M + p.bm - 1) / p.bm) * ((a.N + p.bn - 1) / p.bn);
-    dim3 grid(tiles, p.split, p.nparity);
-    size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB;
+    dim3 grid(tiles * p.split * p.nparity);
+    size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB + 272;   // stages + tap list
     const size_t lds_epi = (size_t)p.bm * (p.bn * 4 + 16);
     if (lds_epi > lds) lds = lds_epi;
     static const bool attr_set = [] {  // 64 KiB of dynamic LDS for the 128x128 tile
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));   // >= 2*(128+128)*128 + 272
         return true;
     }();
     (void)attr_set;
@@ -378,7 +494,8 @@ int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
 }
 
 int run_igemm(int mode, const void *x, const void *w, const float *scale, const float *shift, void *y, int M, int N,
-              int K, int din, int cin, int act, int dtype, int out_dtype, void *ws, size_t ws_bytes, void *stream) {
+              int K, int din, int cin, int act, int dtype, int out_dtype, void *ws, size_t ws_bytes, void *stream,
+              int batch = 1) {
     if (!x || !w || !y) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (out_dtype != VV_F32 && out_dtype != VV_BF16) return VV_ERR_DTYPE;
@@ -389,6 +506,9 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     if ((mode == MODE_CONV || mode == MODE_CONVT) && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const Plan p = make_plan(mode, M, N, K, dtype);
+    const size_t a_bytes = mode == MODE_DENSE ? (size_t)M * K * vv_dtype_size(dtype)
+                           : (size_t)batch * din * din * din * cin * (mode == MODE_FIRST ? 4 : vv_dtype_size(dtype));
+    if (a_bytes >= 0xFFFFFFF0ull || (size_t)p.nparity * N * K * vv_dtype_size(dtype) >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
     if (p.split > 1 && (!ws || ws_bytes < p.ws_bytes || !vv_aligned16(ws))) return VV_ERR_WORKSPACE;
     IgemmArgs a;
     a.A = x; a.W = w; a.Out = y;
@@ -402,6 +522,12 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     a.chunks_per_split = p.cps;
     a.act = act;
     a.out_bf16 = out_dtype == VV_BF16;
+    a.batch = batch;
+    a.a_bytes = (unsigned)a_bytes;
+    a.w_bytes = (unsigned)((size_t)p.nparity * N * K * vv_dtype_size(dtype));
+    a.nsplit = p.split;
+    a.nparity = p.nparity;
+    a.pos_major = use_pos_major(mode, din, batch);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mode == MODE_FIRST) return dtype == VV_BF16 ? launch_t<__bf16, MODE_FIRST>(a, p, st) : launch_t<float, MODE_FIRST>(a, p, st);
     if (dtype == VV_BF16) {
@@ -428,7 +554,7 @@ VV_EXPORT int vv_conv3d_k4s2_fwd(const void *x, const void *w_packed, const floa
     const int o = side / 2;
     if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
     return run_igemm(MODE_CONV, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64 * cin, side, cin, act, dtype,
-                     dtype, workspace, workspace_bytes, stream);
+                     dtype, workspace, workspace_bytes, stream, batch);
 }
 
 VV_EXPORT size_t vv_convT3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype) {
@@ -441,7 +567,7 @@ VV_EXPORT int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const flo
     if (batch <= 0 || side < 1 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
     if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
     return run_igemm(MODE_CONVT, x, w_packed, scale, shift, y, batch * side * side * side, cout, 8 * cin, side, cin, act,
-                     dtype, dtype, workspace, workspace_bytes, stream);
+                     dtype, dtype, workspace, workspace_bytes, stream, batch);
 }
 
 VV_EXPORT size_t vv_dense_workspace_bytes(int m, int n, int k, int dtype) { return make_plan(MODE_DENSE, m, n, k, dtype).ws_bytes; }
@@ -461,5 +587,5 @@ VV_EXPORT int vv_conv3d_first_fwd(const float *x, const void *w_packed, const fl
     if ((long)batch * side * side * side >= (1L << 31)) return VV_ERR_SHAPE;
     const int o = side / 2;
     return run_igemm(MODE_FIRST, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64, side, 1, act, dtype, dtype, nullptr,
-                     0, stream);
+                     0, stream, batch);
 }

@@ -47,7 +47,9 @@ def _check(got, ref, dtname, what):
 
 
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,side,cin,cout', [(2, 8, 64, 128), (3, 4, 128, 64), (1, 16, 64, 128), (5, 2, 256, 512)])
+# B >= 32 switches small grids to position-major rows with padded-tap skipping
+@pytest.mark.parametrize('B,side,cin,cout', [(2, 8, 64, 128), (3, 4, 128, 64), (1, 16, 64, 128), (5, 2, 256, 512),
+                                             (32, 4, 128, 64), (37, 8, 64, 128), (64, 2, 64, 64)])
 def test_conv3d_k4s2(L, dtname, B, side, cin, cout):
     rng = np.random.default_rng(B * 1000 + side)
     dt, tdt = L.DTYPES[dtname], (torch.float32 if dtname == 'f32' else torch.bfloat16)
@@ -71,7 +73,8 @@ def test_conv3d_k4s2(L, dtname, B, side, cin, cout):
 
 
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,side,cin,cout', [(2, 4, 128, 64), (3, 2, 512, 256), (1, 8, 128, 64), (2, 1, 64, 128)])
+@pytest.mark.parametrize('B,side,cin,cout', [(2, 4, 128, 64), (3, 2, 512, 256), (1, 8, 128, 64), (2, 1, 64, 128),
+                                             (33, 2, 64, 128), (40, 4, 64, 64), (64, 1, 64, 64)])
 def test_convT3d_k4s2(L, dtname, B, side, cin, cout):
     rng = np.random.default_rng(B * 77 + side)
     dt, tdt = L.DTYPES[dtname], (torch.float32 if dtname == 'f32' else torch.bfloat16)
