@@ -18,6 +18,8 @@
 // Split-K writes f32 slabs that igemm_splitk_epilogue sums in a fixed order (deterministic).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -368,39 +370,70 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mma_step<T>(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) mma_step<T>(fb[j], fa[i], acc[i][j]);   // D[n][m]: lane = row m, registers walk n
         }
         if (more) lstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    // ---- epilogue.  Accumulators (lane = column n, registers walk rows: row = (q&3) + 8*(q>>2) + 4*h) get the folded
-    // BN + activation, are transposed through LDS into [BM][BN] row-major tiles of the OUTPUT element type, and leave as
-    // 16-byte stores: whole channel rows, coalesced.  Split-K writes raw f32 slabs the same way.
-    const bool to_f32 = a.partial != nullptr || !a.out_bf16;
-    const int es = to_f32 ? 4 : 2;
-    const int pitch = BN * es + 16;   // +16 B: rows 4 apart (the two lane halves of one store) land on different banks
+    // ---- epilogue.  The MFMAs were issued weights-first, so a lane owns ONE output row m = lane & 31 and its 16
+    // registers walk the channels n = (q & 3) + 8 (q >> 2) + 4 (lane >> 5): four consecutive channels per register
+    // quad.  Each quad gets the folded BN + activation as a float4, is packed (8 B of bf16 / 16 B of f32) into a
+    // [BM][BN] row-major LDS tile, and the tile leaves as 16-byte stores: whole channel rows, coalesced.  The
+    // activation / output kind are hoisted into template parameters so the hot code has no per-element branches.
+    const int okind = a.partial ? 2 : (a.out_bf16 ? 0 : 1);
+    const int es = okind == 0 ? 2 : 4;
+    const int pitch = BN * es + 16;
+    auto fill = [&](auto act_c, auto kind_c) {
+        constexpr int ACT = decltype(act_c)::value, KIND = decltype(kind_c)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cl = wn * (BN / 2) + j * 32 + fr;
-        const int n = n0 + cl;
-        float sc = 1.f, sh = 0.f;
-        if (!a.partial && n < a.N) {
-            if (a.scale) sc = a.scale[n];
-            if (a.shift) sh = a.shift[n];
-        }
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * (BN / 2) + j * 32 + 8 * g + 4 * fh;   // tile-local channel of the quad
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (KIND != 2 && n0 + cl < a.N) {
+                    if (a.scale) sc = *reinterpret_cast<const f32x4 *>(a.scale + n0 + cl);
+                    if (a.shift) sh = *reinterpret_cast<const f32x4 *>(a.shift + n0 + cl);
+                }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int rl = wm * (BM / 2) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-                const float v = a.partial ? acc[i][j][q]
-                                          : (to_f32 ? vv_apply_act(acc[i][j][q] * sc + sh, a.act) : vv_apply_act_fast(acc[i][j][q] * sc + sh, a.act));
-                if (to_f32) *reinterpret_cast<float *>(smem + rl * pitch + cl * 4) = v;
-                else *reinterpret_cast<__bf16 *>(smem + rl * pitch + cl * 2) = static_cast<__bf16>(v);
+                for (int i = 0; i < TM; ++i) {
+                    const int rl = wm * (BM / 2) + i * 32 + fr;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][4 * g + e];
+                        if (KIND != 2) {
+                            t = t * sc[e] + sh[e];
+                            if (ACT == VV_ACT_ELU) t = t > 0.f ? t : (KIND == 0 ? __expf(t) - 1.f : expm1f(t));
+                            else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                            else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        }
+                        v[e] = t;
+                    }
+                    if (KIND == 0) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
+                        *reinterpret_cast<bf16x4 *>(smem + rl * pitch + cl * 2) = o;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(smem + rl * pitch + cl * 4) = v;
+                    }
+                }
             }
         }
+    };
+    auto with_kind = [&](auto act_c) {
+        if (okind == 0) fill(act_c, std::integral_constant<int, 0>{});
+        else if (okind == 1) fill(act_c, std::integral_constant<int, 1>{});
+        else fill(act_c, std::integral_constant<int, 2>{});
+    };
+    switch (a.partial ? VV_ACT_NONE : a.act) {
+        case VV_ACT_ELU: with_kind(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: with_kind(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: with_kind(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: with_kind(std::integral_constant<int, VV_ACT_NONE>{}); break;
     }
     __syncthreads();
     const int cpr = BN * es / 16;  // 16-byte chunks per tile row
