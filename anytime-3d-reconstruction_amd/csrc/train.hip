@@ -1,0 +1,531 @@
+// Training-path kernels (reference nolbo.py:1411-1447 `fit`): BatchNorm with batch statistics (forward + backward),
+// activation backward, weight gradients as reduction-over-rows GEMMs on the exact-f32 MFMA, BCE / reparameterisation
+// backward, Adam.  Data gradients reuse the forward implicit-GEMM kernels (the data gradient of a stride-2 conv IS the
+// transposed conv with the same Keras kernel array, and vice versa).  float32 only this round.  gfx950.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// Column reductions over x[R][C] (C % 4 == 0, C <= 1024): workgroup = a slab of rows, lane = 4 channels.
+// MODE 0: sum x, sum x^2.   MODE 1 (backward): du = dy * act'(u), u = x*scale + shift; sum du, sum du * xhat.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                        float *__restrict__ partial, long R, int C, int rows_per_block, int act) {
+    __shared__ float red[2][256 * 4];
+    const int c4n = C >> 2;                  // float4 columns per row
+    const int tid = threadIdx.x;
+    const int rows_par = 256 / c4n > 0 ? 256 / c4n : 1;   // rows handled in parallel (C <= 1024)
+    const int c4 = tid % c4n, rsub = tid / c4n;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1};
+    if (MODE == 1) {
+        sc = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
+        sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+        mu = *reinterpret_cast<const f32x4 *>(mean + c4 * 4);
+        rs = *reinterpret_cast<const f32x4 *>(rstd + c4 * 4);
+    }
+    if (rsub < rows_par) {
+        for (long r = r0 + rsub; r < r1; r += rows_par) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * C + c4 * 4);
+            if (MODE == 0) {
+                s0 += v;
+                s1 += v * v;
+            } else {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = v[e] * sc[e] + sh[e];
+                    float d = g[e];
+                    if (act == VV_ACT_ELU) d *= (u > 0.f ? 1.f : expf(u));
+                    else if (act == VV_ACT_RELU) d = u > 0.f ? d : 0.f;
+                    else if (act == VV_ACT_LRELU) d *= (u > 0.f ? 1.f : 0.3f);
+                    s0[e] += d;
+                    s1[e] += d * ((v[e] - mu[e]) * rs[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][tid * 4 + e] = s0[e]; red[1][tid * 4 + e] = s1[e]; }
+    __syncthreads();
+    if (tid < c4n) {
+        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        for (int k = 0; k < rows_par && k * c4n + tid < 256; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += red[0][(k * c4n + tid) * 4 + e]; b[e] += red[1][(k * c4n + tid) * 4 + e]; }
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 0) * C + tid * 4) = a;
+        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + tid * 4) = b;
+    }
+}
+
+// Forward finalise: batch mean / biased variance -> scale, shift, rstd; moving statistics update (momentum).
+__global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblk, long R, int C, const float *gamma,
+                                         const float *beta, float eps, float momentum, float *mean, float *var, float *rstd,
+                                         float *scale, float *shift, float *moving_mean, float *moving_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    const double m = s / (double)R;
+    double v = ss / (double)R - m * m;
+    if (v < 0.0) v = 0.0;
+    const float r = (float)(1.0 / sqrt(v + (double)eps));
+    mean[c] = (float)m; var[c] = (float)v; rstd[c] = r;
+    scale[c] = gamma[c] * r;
+    shift[c] = beta[c] - (float)m * gamma[c] * r;
+    if (moving_mean) moving_mean[c] = moving_mean[c] * momentum + (float)m * (1.f - momentum);
+    if (moving_var) moving_var[c] = moving_var[c] * momentum + (float)v * (1.f - momentum);
+}
+
+// Backward finalise: dbeta = sum du, dgamma = sum du*xhat
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *dgamma, float *dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)ss;
+}
+
+// y = act(x*scale + shift)
+__global__ void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                  float *__restrict__ y, long n4, int C, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = vv_apply_act(v[e] * sc[e] + sh[e], act);
+        reinterpret_cast<f32x4 *>(y)[i] = o;
+    }
+}
+
+// dx = gamma*rstd * (du - dbeta/R - xhat*dgamma/R),  du = dy*act'(x*scale+shift)
+__global__ void bn_act_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, float *__restrict__ dx,
+                                  long n4, int C, float invR, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i], g = reinterpret_cast<const f32x4 *>(dy)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = v[e] * scale[c + e] + shift[c + e];
+            float d = g[e];
+            if (act == VV_ACT_ELU) d *= (u > 0.f ? 1.f : expf(u));
+            else if (act == VV_ACT_RELU) d = u > 0.f ? d : 0.f;
+            else if (act == VV_ACT_LRELU) d *= (u > 0.f ? 1.f : 0.3f);
+            const float xh = (v[e] - mean[c + e]) * rstd[c + e];
+            o[e] = scale[c + e] * (d - dbeta[c + e] * invR - xh * dgamma[c + e] * invR);
+        }
+        reinterpret_cast<f32x4 *>(dx)[i] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+// dW[m][n] = sum_r A[r][m] * G[r][n]   (reduction over rows r = samples x positions), exact-f32 MFMA 32x32x2.
+//   AMODE 0: A[r][m] dense, row pitch lda                                  (Dense kernels, pooled / panel layers)
+//   AMODE 1: A[r][(t,ci)] = src[b, 2o-1+t, ci] (zero in the SAME padding), r = (b,o) over the HALF-size grid: the
+//            weight gradient of a stride-2 Conv3D (src = layer input, G = dL/d(conv out)) -> Keras [t][ci][co];
+//            with src = dL/d(out) and G = layer input it is the weight gradient of a stride-2 Conv3DTranspose
+//            -> Keras [t][co][ci].
+//   AMODE 2: as 1 with one source channel (m = tap): first conv / last transposed conv.
+// Tile 64 (m) x BN (n), 4 waves (2x2), reduction chunks of 32 rows staged in LDS as [r][m] / [r][n] (the f32 MFMA
+// wants lane = m, k = row: rows of the chunk ARE k, no transposition needed).  grid.y splits the reduction; slabs are
+// summed in split order by wgrad_reduce_kernel (deterministic).
+struct WgradArgs {
+    const float *A;
+    const float *G;
+    float *slabs;       // [splits][M][N]
+    long R;             // reduction rows
+    int M, N;
+    int lda;            // AMODE 0 row pitch (elements)
+    int din_log2, cin;  // AMODE 1/2: source grid side (log2) and channels
+    int rows_per_split;
+};
+
+template <int AMODE, int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int BM = 64, BR = 32, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) float As[BR][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Gs[BR][BN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long r_begin = (long)blockIdx.y * a.rows_per_split;
+    const long r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
+    const int li = a.din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+    // staging roles: A chunk = 32 rows x 64 floats = 512 float4 slots -> 2 per thread; G chunk = 32 x BN -> BN/32 per thread
+    const int fr = lane & 31, fh = lane >> 5;
+    for (long rc = r_begin; rc < r_end; rc += BR) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int slot = tid + 256 * it, rr = slot >> 4, c4 = slot & 15;
+            const long r = rc + rr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < r_end) {
+                if (AMODE == 0) {
+                    const int m = m0 + c4 * 4;
+                    if (m < a.M) v = *reinterpret_cast<const f32x4 *>(a.A + r * a.lda + m);
+                } else {
+                    const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
+                    const long b = r >> (3 * lo);
+                    if (AMODE == 1) {
+                        const int m = m0 + c4 * 4, t = m / a.cin, ci = m % a.cin;   // cin % 64 == 0: a tile stays inside one tap
+                        const int id = 2 * od - 1 + (t >> 4), ih = 2 * oh - 1 + ((t >> 2) & 3), iw = 2 * ow - 1 + (t & 3);
+                        if (m < a.M && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
+                            v = *reinterpret_cast<const f32x4 *>(a.A + ((((b << li) + id << li) + ih << li) + iw) * a.cin + ci);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int t = c4 * 4 + e;
+                            const int id = 2 * od - 1 + (t >> 4), ih = 2 * oh - 1 + ((t >> 2) & 3), iw = 2 * ow - 1 + (t & 3);
+                            if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
+                                v[e] = a.A[(((b << li) + id << li) + ih << li) + iw];
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4 *>(&As[rr][c4 * 4]) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < BN / 32; ++it) {
+            const int slot = tid + 256 * it, rr = slot / (BN / 4), c4 = slot % (BN / 4);
+            const long r = rc + rr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int nn = n0 + c4 * 4;
+            if (r < r_end && nn < a.N) v = *reinterpret_cast<const f32x4 *>(a.G + r * a.N + nn);
+            *reinterpret_cast<f32x4 *>(&Gs[rr][c4 * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BR; k += 2) {
+            const float av = As[k + fh][wm * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float gv = Gs[k + fh][wn * (BN / 2) + j * 32 + fr];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gv, acc[j], 0, 0, 0);   // D[m][n]: lane = n, regs walk m
+            }
+        }
+        __syncthreads();
+    }
+    float *slab = a.slabs + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nn = n0 + wn * (BN / 2) + j * 32 + fr;
+        if (nn >= a.N) continue;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+            if (m < a.M) slab[(size_t)m * a.N + nn] = acc[j][q];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, long n, int splits, float alpha,
+                                    int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+        out[i] = accumulate ? out[i] + alpha * s : alpha * s;
+    }
+}
+
+// Adjoints of the two "layer as a dense panel" packings (vv_pack_conv_k4s1_meanpool / vv_pack_convT_k4s1_dense).
+__global__ void unpack_meanpool_grad_kernel(const float *__restrict__ dpanel, float *__restrict__ dw, int side, int cin, int cout) {
+    // dw[t][ci][co] = (1/S^3) sum_{(i,o) : i - o + 1 = t per axis} dpanel[co][i*cin + ci]
+    const int S3 = side * side * side;
+    const long total = (long)64 * cin * cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % cout), ci = (int)((idx / cout) % cin), t = (int)(idx / ((long)cout * cin));
+        const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
+        float s = 0.f;
+        for (int od = 0; od < side; ++od) {
+            const int id = od + td - 1;
+            if ((unsigned)id >= (unsigned)side) continue;
+            for (int oh = 0; oh < side; ++oh) {
+                const int ih = oh + th - 1;
+                if ((unsigned)ih >= (unsigned)side) continue;
+                for (int ow = 0; ow < side; ++ow) {
+                    const int iw = ow + tw - 1;
+                    if ((unsigned)iw >= (unsigned)side) continue;
+                    s += dpanel[(size_t)co * S3 * cin + (size_t)((id * side + ih) * side + iw) * cin + ci];
+                }
+            }
+        }
+        dw[idx] = s / (float)S3;
+    }
+}
+
+__global__ void unpack_convT_dense_grad_kernel(const float *__restrict__ dpanel, float *__restrict__ dw, int side, int cin, int cout) {
+    // dw[t][co][ci] = sum_{(o,j) : o - j + 1 = t per axis} dpanel[(o,co)][(j,ci)]
+    const int S3 = side * side * side, K = S3 * cin;
+    const long total = (long)64 * cin * cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % cin), co = (int)((idx / cin) % cout), t = (int)(idx / ((long)cout * cin));
+        const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
+        float s = 0.f;
+        for (int jd = 0; jd < side; ++jd) {
+            const int od = jd + td - 1;
+            if ((unsigned)od >= (unsigned)side) continue;
+            for (int jh = 0; jh < side; ++jh) {
+                const int oh = jh + th - 1;
+                if ((unsigned)oh >= (unsigned)side) continue;
+                for (int jw = 0; jw < side; ++jw) {
+                    const int ow = jw + tw - 1;
+                    if ((unsigned)ow >= (unsigned)side) continue;
+                    const int o = (od * side + oh) * side + ow, j = (jd * side + jh) * side + jw;
+                    s += dpanel[((size_t)o * cout + co) * K + (size_t)j * cin + ci];
+                }
+            }
+        }
+        dw[idx] = s;
+    }
+}
+
+__global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = bx + j, c = by + threadIdx.x;   // out is [cols][rows]
+        if (r < cols && c < rows) out[(size_t)r * rows + c] = tile[threadIdx.x][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ losses backward
+// d(mean_b bce_b)/dlogit: bce = -(g y log q + (1-g)(1-y) log(1-q)), q = clip(sigmoid(l), eps, 1-eps); the clip passes
+// the gradient only inside [eps, 1-eps] (tf.clip_by_value).  function.py:73-82, nolbo.py:1432-1433.
+__global__ void bce_bwd_kernel(const float *__restrict__ probs, const float *__restrict__ target, float *__restrict__ dlogit,
+                               long n, float gamma, float epsilon, float inv_batch) {
+    const float hi = 1.0f - epsilon;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float p = probs[i], y = target[i];
+        float g = 0.f;
+        if (p >= epsilon && p <= hi) g = (-gamma * y * (1.f - p) + (1.f - gamma) * (1.f - y) * p) * inv_batch;
+        dlogit[i] = g;
+    }
+}
+
+// Backward of slice | clip | sampling | dropout | mean_b KL  (nolbo.py:1417-1436; function.py:35-38, 84-98)
+__global__ void reparam_kl_bwd_kernel(const float *__restrict__ enc_out, const float *__restrict__ eps, const float *__restrict__ dz,
+                                      const float *__restrict__ drop_mask, float drop_scale, float *__restrict__ d_enc_out,
+                                      int B, int L, float inv_batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, j = i % L;
+    const float mu = enc_out[(size_t)b * 2 * L + j], raw = enc_out[(size_t)b * 2 * L + L + j];
+    const float lv = fminf(fmaxf(raw, -10.f), 10.f);
+    float g = dz[i];
+    if (drop_mask) g *= drop_mask[i] * drop_scale;
+    const float e = expf(lv);
+    d_enc_out[(size_t)b * 2 * L + j] = g + mu * inv_batch;
+    const float dlv = g * (0.5f * sqrtf(e) * eps[i]) + 0.5f * (e - 1.f) * inv_batch;
+    d_enc_out[(size_t)b * 2 * L + L + j] = (raw >= -10.f && raw <= 10.f) ? dlv : 0.f;
+}
+
+// Keras Adam (beta1, beta2, epsilon 1e-7; lr_t = lr*sqrt(1-b2^t)/(1-b1^t)):  nolbo.py:1402, 1441
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            long n, float lr_t, float b1, float b2, float eps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long R, int C) {
+    // out[c] = sum_r x[r][c] (Dense bias gradient; R = batch, small)
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (long r = 0; r < R; ++r) s += x[r * C + c];
+    out[c] = s;
+}
+
+inline int grid_1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+inline int bn_blocks(long R) {
+    long nb = (R + 255) / 256;
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+
+}  // namespace
+
+VV_EXPORT size_t vv_bn_workspace_bytes(long rows, int channels) { return (size_t)bn_blocks(rows) * 2 * channels * sizeof(float); }
+
+VV_EXPORT int vv_bn_train_stats(const float *x, long rows, int channels, const float *gamma, const float *beta, float eps,
+                                float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
+                                float *moving_mean, float *moving_var, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !gamma || !beta || !mean || !var || !rstd || !scale || !shift) return VV_ERR_NULL;
+    if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
+    if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = bn_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    float *part = reinterpret_cast<float *>(workspace);
+    VV_LAUNCH((bn_reduce_kernel<0>), dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, part, rows, channels, rpb, 0);
+    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nb, rows, channels, gamma, beta, eps,
+              momentum, mean, var, rstd, scale, shift, moving_mean, moving_var);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_bn_act_fwd(const float *x, const float *scale, const float *shift, float *y, long rows, int channels, int act,
+                            void *stream) {
+    if (!x || !scale || !shift || !y) return VV_ERR_NULL;
+    if (rows <= 0 || channels <= 0 || channels % 4) return VV_ERR_SHAPE;
+    const long n4 = rows * channels / 4;
+    VV_LAUNCH(bn_act_fwd_kernel, dim3(grid_1d(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, scale, shift, y, n4, channels, act);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_bn_act_bwd(const float *x, const float *dy, const float *scale, const float *shift, const float *mean,
+                            const float *rstd, float *dgamma, float *dbeta, float *dx, long rows, int channels, int act,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !dy || !scale || !shift || !mean || !rstd || !dgamma || !dbeta || !dx) return VV_ERR_NULL;
+    if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
+    if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = bn_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    float *part = reinterpret_cast<float *>(workspace);
+    VV_LAUNCH((bn_reduce_kernel<1>), dim3(nb), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, rows, channels, rpb, act);
+    VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
+    const long n4 = rows * channels / 4;
+    VV_LAUNCH(bn_act_bwd_kernel, dim3(grid_1d(n4)), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dgamma, dbeta, dx, n4, channels,
+              1.0f / (float)rows, act);
+    return vv_launch_status();
+}
+
+namespace {
+struct WgradPlan { int bn, splits, rps; size_t ws; };
+WgradPlan wgrad_plan(long R, int M, int N) {
+    WgradPlan p;
+    p.bn = (N % 128 == 0) ? 128 : 64;
+    const long tiles = (long)((M + 63) / 64) * ((N + p.bn - 1) / p.bn);
+    long chunks = (R + 31) / 32;
+    long splits = 1;
+    while (tiles * splits < 1024 && splits * 2 <= chunks && splits < 256) splits *= 2;
+    p.rps = (int)(((chunks + splits - 1) / splits) * 32);
+    p.splits = (int)((R + p.rps - 1) / p.rps);
+    p.ws = (size_t)p.splits * M * N * sizeof(float);
+    return p;
+}
+
+template <int AMODE>
+int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha, int accumulate, hipStream_t st) {
+    const int tiles = ((a.M + 63) / 64) * ((a.N + p.bn - 1) / p.bn);
+    if (p.bn == 128) VV_LAUNCH((wgrad_kernel<AMODE, 128>), dim3(tiles, p.splits), dim3(256), 0, st, a);
+    else VV_LAUNCH((wgrad_kernel<AMODE, 64>), dim3(tiles, p.splits), dim3(256), 0, st, a);
+    const long n = (long)a.M * a.N;
+    VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, a.slabs, out, n, p.splits, alpha, accumulate);
+    return vv_launch_status();
+}
+}  // namespace
+
+VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) { return wgrad_plan(rows, m, n).ws; }
+
+VV_EXPORT int vv_wgrad_dense(const float *a, const float *g, float *dw, long rows, int m, int n, int lda, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    if (!a || !g || !dw) return VV_ERR_NULL;
+    if (rows <= 0 || m <= 0 || n <= 0 || m % 4 || n % 4 || lda % 4) return VV_ERR_SHAPE;
+    const WgradPlan p = wgrad_plan(rows, m, n);
+    if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
+    WgradArgs w{a, g, reinterpret_cast<float *>(workspace), rows, m, n, lda, 0, 0, p.rps};
+    return launch_wgrad<0>(w, p, dw, 1.f, 0, reinterpret_cast<hipStream_t>(stream));
+}
+
+VV_EXPORT int vv_wgrad_conv_k4s2(const float *src, const float *g, float *dw, int batch, int side, int cin, int cout,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    if (!src || !g || !dw) return VV_ERR_NULL;
+    if (batch <= 0 || side < 2 || !vv_is_pow2(side) || cout % 4 || (cin != 1 && cin % 64)) return VV_ERR_SHAPE;
+    const int o = side / 2;
+    const long rows = (long)batch * o * o * o;
+    const int m = 64 * cin;
+    const WgradPlan p = wgrad_plan(rows, m, cout);
+    if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
+    WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps};
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return cin == 1 ? launch_wgrad<2>(w, p, dw, 1.f, 0, st) : launch_wgrad<1>(w, p, dw, 1.f, 0, st);
+}
+
+VV_EXPORT int vv_unpack_meanpool_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream) {
+    if (!dpanel || !dw) return VV_ERR_NULL;
+    VV_LAUNCH(unpack_meanpool_grad_kernel, dim3(grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+              dpanel, dw, side, cin, cout);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_unpack_convT_dense_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream) {
+    if (!dpanel || !dw) return VV_ERR_NULL;
+    VV_LAUNCH(unpack_convT_dense_grad_kernel, dim3(grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+              dpanel, dw, side, cin, cout);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_transpose_f32(const float *in, float *out, int rows, int cols, void *stream) {
+    if (!in || !out) return VV_ERR_NULL;
+    if (rows <= 0 || cols <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, reinterpret_cast<hipStream_t>(stream), in, out, rows, cols);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_bce_bwd(const float *probs, const float *target, float *dlogit, int batch, long voxels, float gamma, float epsilon,
+                         float inv_batch, void *stream) {
+    if (!probs || !target || !dlogit) return VV_ERR_NULL;
+    if (batch <= 0 || voxels <= 0) return VV_ERR_SHAPE;
+    const long n = (long)batch * voxels;
+    VV_LAUNCH(bce_bwd_kernel, dim3(grid_1d(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), probs, target, dlogit, n, gamma,
+              epsilon, inv_batch);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_reparam_kl_bwd(const float *enc_out, const float *eps, const float *dz, const float *drop_mask, float drop_scale,
+                                float *d_enc_out, int batch, int latent, float inv_batch, void *stream) {
+    if (!enc_out || !eps || !dz || !d_enc_out) return VV_ERR_NULL;
+    if (batch <= 0 || latent <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(reparam_kl_bwd_kernel, dim3((batch * latent + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), enc_out,
+              eps, dz, drop_mask, drop_scale, d_enc_out, batch, latent, inv_batch);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_adam_step(float *param, const float *grad, float *m, float *v, long n, float lr_t, float beta1, float beta2,
+                           float epsilon, void *stream) {
+    if (!param || !grad || !m || !v) return VV_ERR_NULL;
+    if (n <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(adam_kernel, dim3(grid_1d(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v, n, lr_t, beta1,
+              beta2, epsilon);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_colsum(const float *x, float *out, long rows, int cols, void *stream) {
+    if (!x || !out) return VV_ERR_NULL;
+    if (rows <= 0 || cols <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, rows, cols);
+    return vv_launch_status();
+}

@@ -77,6 +77,25 @@ class _ModelnetBase(object):
             _L.call('vv_category_accuracy', _L.ptr(idx), _L.ptr(onehot), C, _L.ptr(acc), B, _st())
         return idx, acc
 
+    def _fit(self, inputs, eps, drop_mask, drop_rate):
+        """One optimisation step (GradientTape + Adam.apply_gradients of the reference) through voxvae.train.Trainer."""
+        from voxvae import train as _T
+        if getattr(self, '_trainer', None) is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            self._trainer = _T.Trainer(self._enc_eng, self._dec_eng, self._variational, self._learning_rate, world_size=world)
+        input_images, output_images = inputs
+        x, y = self._dev(input_images), self._dev(output_images)
+        mask, scale = None, 1.0
+        if self._dropout:      # reference nolbo.py:1423-1425: rate ~ U[0,1) per step, inverted dropout on z
+            rate = float(np.random.rand()) if drop_rate is None else float(drop_rate)
+            Lz = self._enc_backbone_str['z_category_dim']
+            if drop_mask is None:
+                drop_mask = (np.random.rand(x.shape[0], Lz) >= rate).astype('float32')
+            mask, scale = self._dev(drop_mask), 1.0 / (1.0 - rate)
+        kl, stats, m = self._trainer.step(x, y, None if eps is None else self._dev(eps), mask, scale)
+        return kl, m
+
     # ---------------------------------------------------------------- public API (reference signatures)
     def getEval(self, inputs, category_vectors=None, training=False, missing_prob=0.0, *, _eps=None, _mask=None, _eps2=None):
         """reference nolbo.py:1449-1528 (VAE) / :1260-1332 (AE): returns the 10-tuple
@@ -195,9 +214,10 @@ class nolboSingleObject_modelnet_category_AE(_ModelnetBase):
         self._learning_rate = learning_rate
         self._buildModel()
 
-    def fit(self, inputs):
+    def fit(self, inputs, *, _mask=None, _rate=None):
         """reference nolbo.py:1230-1258 -> (loss_shape, pr, rc)."""
-        raise NotImplementedError('training path (BN batch statistics, backward, Adam) is not built yet')
+        _, m = self._fit(inputs, None, _mask, _rate)
+        return DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
 
 
 class nolboSingleObject_modelnet_category_VAE(_ModelnetBase):
@@ -214,6 +234,7 @@ class nolboSingleObject_modelnet_category_VAE(_ModelnetBase):
         self._learning_rate = learning_rate
         self._buildModel()
 
-    def fit(self, inputs):
+    def fit(self, inputs, *, _eps=None, _mask=None, _rate=None):
         """reference nolbo.py:1411-1447 -> (loss_kl, loss_shape, pr, rc)."""
-        raise NotImplementedError('training path (BN batch statistics, backward, Adam) is not built yet')
+        kl, m = self._fit(inputs, _eps, _mask, _rate)
+        return DeviceArray(kl.mean()), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])

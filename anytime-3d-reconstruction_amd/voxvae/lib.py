@@ -16,7 +16,7 @@ VV_F32, VV_BF16 = 0, 1
 ACT = {None: 0, 'None': 0, 'linear': 0, 'elu': 1, 'relu': 2, 'lrelu': 3}
 DTYPES = {'f32': VV_F32, 'fp32': VV_F32, 'float32': VV_F32, 'bf16': VV_BF16, 'bfloat16': VV_BF16}
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes); mirrors include/voxvae.h one to one (tests/test_abi.py checks the header)
 SIGNATURES = {
@@ -48,6 +48,20 @@ SIGNATURES = {
     'vv_voxel_precision_recall': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, ctypes.c_long, _vp]),
     'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
+    'vv_bn_workspace_bytes': (_sz, [_l, _i]),
+    'vv_bn_train_stats': (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'vv_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    'vv_bn_act_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _sz, _vp]),
+    'vv_wgrad_workspace_bytes': (_sz, [_l, _i, _i]),
+    'vv_wgrad_dense': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_wgrad_conv_k4s2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_unpack_meanpool_grad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_unpack_convT_dense_grad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
+    'vv_colsum': (_i, [_vp, _vp, _l, _i, _vp]),
+    'vv_bce_bwd': (_i, [_vp, _vp, _vp, _i, _l, _f, _f, _f, _vp]),
+    'vv_reparam_kl_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _f, _vp]),
+    'vv_adam_step': (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp]),
 }
 
 

@@ -1,0 +1,283 @@
+"""Training step of the modelnet VAE / AE (reference src/module/nolbo.py:1411-1447 / 1230-1258) on the C ABI.
+
+Forward with batch-statistics BatchNorm, backward (data gradients through the forward implicit-GEMM kernels,
+weight gradients through the reduction-over-rows MFMA kernel), Keras Adam.  float32 only this round.
+
+Data parallel (modelled on the reference's only multi-GPU path, src/module/AE3D.py:46-48, 86-104):
+one process per GPU, each rank runs its own batch shard with its OWN BatchNorm statistics, the loss is scaled
+by the GLOBAL batch, and the gradients are summed across ranks by one bucketed all-reduce (RCCL over xGMI with
+backend 'nccl'; gloo in the CPU tests of the bucketing logic) before Adam runs on every replica.
+"""
+import ctypes
+
+import torch
+
+from . import engine as E
+from . import lib as L
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99          # Keras BatchNormalization defaults
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # tf.keras.optimizers.Adam defaults
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class GradBuckets:
+    """Flat gradient storage: every trainable tensor's gradient is a view into one of a few large float32
+    buffers, so the cross-rank sum is a handful of large all-reduces (per-link-bound xGMI rings want few, big
+    messages) issued in backward order.  Pure tensor bookkeeping: usable (and tested) on CPU with gloo."""
+
+    def __init__(self, named_shapes, device, bucket_bytes=32 << 20):
+        self.views, self.buckets = {}, []
+        cur, cur_n = [], 0
+        plan = []
+        for name, shape in named_shapes:
+            n = 1
+            for s in shape:
+                n *= int(s)
+            n_pad = (n + 3) // 4 * 4              # keep every view 16-byte aligned
+            if cur and (cur_n + n_pad) * 4 > bucket_bytes:
+                plan.append((cur, cur_n))
+                cur, cur_n = [], 0
+            cur.append((name, shape, n, cur_n))
+            cur_n += n_pad
+        if cur:
+            plan.append((cur, cur_n))
+        for items, total in plan:
+            buf = torch.zeros(total, dtype=torch.float32, device=device)
+            self.buckets.append(buf)
+            for name, shape, n, off in items:
+                self.views[name] = buf[off:off + n].view(*shape)
+
+    def all_reduce(self, group=None):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in self.buckets]
+        for w in works:
+            w.wait()
+
+
+class _BN:
+    """Per-layer BatchNorm training state (batch statistics + folded scale/shift) on device."""
+
+    def __init__(self, c, device):
+        self.c = c
+        for n in ('mean', 'var', 'rstd', 'scale', 'shift'):
+            setattr(self, n, torch.empty(c, dtype=torch.float32, device=device))
+
+
+class Trainer:
+    def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None):
+        if enc.dt != L.VV_F32 or dec.dt != L.VV_F32:
+            raise NotImplementedError("training runs in 'f32' (exact-f32 MFMA) this round; build the model with dtype 'f32'")
+        self.enc, self.dec, self.var, self.lr = enc, dec, variational, float(learning_rate)
+        self.dev = enc.device
+        self.world, self.group = int(world_size), group
+        self.t = 0
+        self.debug = None          # set to a dict to capture intermediate tensors of the next step (tests)
+        self.ws = E._Workspace(self.dev)
+        names = [('enc/' + k, v.shape) for k, v in enc.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
+        names += [('dec/' + k, v.shape) for k, v in dec.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
+        # backward order: decoder tail first ... encoder head last
+        self.order = list(reversed(names))
+        self.grads = GradBuckets(self.order, self.dev)
+        self.m = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
+        self.v = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
+
+    # ------------------------------------------------------------------ helpers
+    def _p(self, name):
+        eng, key = (self.enc, name[4:]) if name.startswith('enc/') else (self.dec, name[4:])
+        return eng.params[key]
+
+    def _g(self, name):
+        return self.grads.views[name]
+
+    def _empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def _bn_fwd(self, c, rows, ch, eng, prefix, act):
+        bn = _BN(ch, self.dev)
+        p = eng.params
+        ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, ch))
+        L.call('vv_bn_train_stats', L.ptr(c), rows, ch, L.ptr(p[prefix + '/gamma']), L.ptr(p[prefix + '/beta']), BN_EPS, BN_MOMENTUM,
+               L.ptr(bn.mean), L.ptr(bn.var), L.ptr(bn.rstd), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(p[prefix + '/moving_mean']),
+               L.ptr(p[prefix + '/moving_variance']), L.ptr(ws), ws.numel(), _st())
+        h = torch.empty_like(c)
+        L.call('vv_bn_act_fwd', L.ptr(c), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(h), rows, ch, act, _st())
+        return h, bn
+
+    def _bn_bwd(self, c, dh, bn, rows, gname, bname, act):
+        dc = torch.empty_like(c)
+        ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, bn.c))
+        L.call('vv_bn_act_bwd', L.ptr(c), L.ptr(dh), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(bn.mean), L.ptr(bn.rstd),
+               L.ptr(self._g(gname)), L.ptr(self._g(bname)), L.ptr(dc), rows, bn.c, act, L.ptr(ws), ws.numel(), _st())
+        return dc
+
+    def _dense(self, x, panel, m, n, k, shift=None):
+        y = self._empty(m, n)
+        ws = self.ws.get(L.load().vv_dense_workspace_bytes(m, n, k, L.VV_F32))
+        L.call('vv_dense_fwd', L.ptr(x), L.ptr(panel), None, L.ptr(shift), L.ptr(y), m, n, k, 0, L.VV_F32, L.VV_F32, L.ptr(ws),
+               ws.numel(), _st())
+        return y
+
+    def _wgrad_dense(self, a, g, out, rows, m, n):
+        ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(rows, m, n))
+        L.call('vv_wgrad_dense', L.ptr(a), L.ptr(g), L.ptr(out), rows, m, n, m, L.ptr(ws), ws.numel(), _st())
+
+    def _wgrad_conv(self, src, g, out, batch, side, cin, cout):
+        o = side // 2
+        ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(batch * o ** 3, 64 * cin, cout))
+        L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), batch, side, cin, cout, L.ptr(ws), ws.numel(), _st())
+
+    # ------------------------------------------------------------------ one step
+    def step(self, x, y, eps=None, drop_mask=None, drop_scale=1.0):
+        """x, y: float32 CUDA [B,D,D,D,1].  Returns device tensors (loss_kl or None, stats [B,4], metrics [4])."""
+        enc, dec, dev = self.enc, self.dec, self.dev
+        enc.ensure_packed()
+        dec.ensure_packed()
+        B, D = x.shape[0], enc.D
+        fe, fd = enc.filters, dec.filters
+        act = enc.act
+        inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
+        st = _st()
+        f32 = L.VV_F32
+
+        # ---------------- encoder forward (raw conv -> batch stats -> BN + act)
+        ec, eh, ebn = [], [], []
+        side = D // 2
+        c = self._empty(B, side, side, side, fe[0])
+        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(enc.packed['w0']), None, None, L.ptr(c), B, D, fe[0], 0, f32, st)
+        h, bn = self._bn_fwd(c, B * side ** 3, fe[0], enc, 'bn0', act)
+        ec.append(c); eh.append(h); ebn.append(bn)
+        for i in range(1, len(fe) - 1):
+            ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, fe[i - 1], fe[i], f32))
+            c = self._empty(B, side // 2, side // 2, side // 2, fe[i])
+            L.call('vv_conv3d_k4s2_fwd', L.ptr(eh[-1]), L.ptr(enc.packed['w%d' % i]), None, None, L.ptr(c), B, side, fe[i - 1], fe[i],
+                   0, f32, L.ptr(ws), ws.numel(), st)
+            side //= 2
+            h, bn = self._bn_fwd(c, B * side ** 3, fe[i], enc, 'bn%d' % i, act)
+            ec.append(c); eh.append(h); ebn.append(bn)
+        ne = len(fe) - 1
+        K5 = side ** 3 * fe[ne - 1]
+        enc_out = self._dense(eh[-1], enc.packed['w%d' % ne], B, fe[ne], K5)
+        Sside_e = side
+
+        # ---------------- latent
+        Lz = dec.L
+        if self.var:
+            if eps is None:
+                eps = torch.randn(B, Lz, dtype=torch.float32, device=dev)
+            z, _, kl, _, _ = E.reparam_kl(enc_out, eps, Lz, f32, drop_mask, drop_scale)
+        else:
+            z, kl = enc_out, None
+            if drop_mask is not None:
+                raise NotImplementedError('latent dropout for the AE class')
+
+        # ---------------- decoder forward
+        S, ch = dec.S, dec.ch
+        lin = S ** 3 * ch
+        c_d0 = self._dense(z, dec.packed['wd'], B, lin, Lz, shift=dec.params['dense/bias'])
+        t0, bn_d0 = self._bn_fwd(c_d0, B, lin, dec, 'bn_dense', act)
+        n1 = S ** 3 * fd[0]
+        c_d1 = self._dense(t0, dec.packed['w0'], B, n1, lin)
+        h_d1, bn_d1 = self._bn_fwd(c_d1, B * S ** 3, fd[0], dec, 'bnT0', act)
+        dc_, dh_, dbn = [c_d1], [h_d1], [bn_d1]
+        side = S
+        for i in range(1, len(fd) - 1):
+            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, fd[i - 1], fd[i], f32))
+            c = self._empty(B, 2 * side, 2 * side, 2 * side, fd[i])
+            L.call('vv_convT3d_k4s2_fwd', L.ptr(dh_[-1]), L.ptr(dec.packed['w%d' % i]), None, None, L.ptr(c), B, side, fd[i - 1], fd[i],
+                   0, f32, L.ptr(ws), ws.numel(), st)
+            side *= 2
+            h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
+            dc_.append(c); dh_.append(h); dbn.append(bn)
+        nd = len(fd) - 1
+        w5 = dec.params['convT%d/kernel' % nd]
+        probs = self._empty(B, D, D, D, 1)
+        stats = self._empty(B, 4)
+        ws = self.ws.get(L.load().vv_convT3d_final_bce_workspace_bytes(B, side))
+        L.call('vv_convT3d_final_bce_fwd', L.ptr(dh_[-1]), L.ptr(w5), L.ptr(y), L.ptr(probs), None, L.ptr(stats), B, side, fd[nd - 1],
+               0.6, 1e-7, f32, L.ptr(ws), ws.numel(), st)
+        metrics = E.shape_metrics(stats)
+
+        # ---------------- backward: decoder tail
+        dlogit = self._empty(B, D, D, D, 1)
+        L.call('vv_bce_bwd', L.ptr(probs), L.ptr(y), L.ptr(dlogit), B, D ** 3, 0.6, 1e-7, inv_gb, st)
+        cl = fd[nd - 1]
+        self._wgrad_conv(dlogit, dh_[-1], self._g('dec/convT%d/kernel' % nd), B, D, 1, cl)        # [64 taps][cl] = Keras [4,4,4,1,cl]
+        w5p = self._empty(cl, 64)
+        L.call('vv_pack_conv_k4', L.ptr(w5), L.ptr(w5p), 1, cl, f32, st)
+        dh = self._empty(B, side, side, side, cl)
+        L.call('vv_conv3d_first_fwd', L.ptr(dlogit), L.ptr(w5p), None, None, L.ptr(dh), B, D, cl, 0, f32, st)
+        for i in range(nd - 1, 0, -1):                       # stride-2 transposed convs
+            cin, cout = fd[i - 1], fd[i]
+            dcv = self._bn_bwd(dc_[i], dh, dbn[i], B * side ** 3, 'dec/bnT%d/gamma' % i, 'dec/bnT%d/beta' % i, act)
+            wk = dec.params['convT%d/kernel' % i]            # Keras [4,4,4,cout,cin]
+            self._wgrad_conv(dcv, dh_[i - 1], self._g('dec/convT%d/kernel' % i), B, side, cout, cin)
+            wp = self._empty(cin, 64 * cout)                 # read as a forward conv kernel [4,4,4,Cin_c=cout,Cout_c=cin]
+            L.call('vv_pack_conv_k4', L.ptr(wk), L.ptr(wp), cout, cin, f32, st)
+            ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, cout, cin, f32))
+            dh = self._empty(B, side // 2, side // 2, side // 2, cin)
+            L.call('vv_conv3d_k4s2_fwd', L.ptr(dcv), L.ptr(wp), None, None, L.ptr(dh), B, side, cout, cin, 0, f32, L.ptr(ws), ws.numel(), st)
+            side //= 2
+        # D1 (dense panel over the S^3 seed)
+        dcv = self._bn_bwd(c_d1, dh, bn_d1, B * S ** 3, 'dec/bnT0/gamma', 'dec/bnT0/beta', act)
+        dpanel = self._empty(n1, lin)
+        self._wgrad_dense(dcv, t0, dpanel, B, n1, lin)
+        L.call('vv_unpack_convT_dense_grad', L.ptr(dpanel), L.ptr(self._g('dec/convT0/kernel')), S, ch, fd[0], st)
+        w0t = self._empty(lin, n1)
+        L.call('vv_transpose_f32', L.ptr(dec.packed['w0']), L.ptr(w0t), n1, lin, st)
+        dt0 = self._dense(dcv, w0t, B, lin, n1)
+        # D0 (Dense + bias)
+        dcv0 = self._bn_bwd(c_d0, dt0, bn_d0, B, 'dec/bn_dense/gamma', 'dec/bn_dense/beta', act)
+        L.call('vv_colsum', L.ptr(dcv0), L.ptr(self._g('dec/dense/bias')), B, lin, st)
+        self._wgrad_dense(z, dcv0, self._g('dec/dense/kernel'), B, Lz, lin)
+        dz = self._dense(dcv0, dec.params['dense/kernel'], B, Lz, lin)      # Keras [L][lin] is the [N][K] panel of the data gradient
+
+        # ---------------- backward: latent
+        if self.var:
+            de = self._empty(B, 2 * Lz)
+            L.call('vv_reparam_kl_bwd', L.ptr(enc_out), L.ptr(eps), L.ptr(dz), L.ptr(drop_mask), float(drop_scale), L.ptr(de), B, Lz,
+                   inv_gb, st)
+        else:
+            de = dz
+        # ---------------- backward: encoder
+        E_out = fe[ne]
+        dpanel = self._empty(E_out, K5)
+        self._wgrad_dense(de, eh[-1], dpanel, B, E_out, K5)
+        L.call('vv_unpack_meanpool_grad', L.ptr(dpanel), L.ptr(self._g('enc/conv%d/kernel' % ne)), Sside_e, fe[ne - 1], E_out, st)
+        wet = self._empty(K5, E_out)
+        L.call('vv_transpose_f32', L.ptr(enc.packed['w%d' % ne]), L.ptr(wet), E_out, K5, st)
+        dh = self._dense(de, wet, B, K5, E_out)
+        side = Sside_e
+        for i in range(ne - 1, 0, -1):                       # stride-2 convs
+            cin, cout = fe[i - 1], fe[i]
+            dcv = self._bn_bwd(ec[i], dh, ebn[i], B * side ** 3, 'enc/bn%d/gamma' % i, 'enc/bn%d/beta' % i, act)
+            wk = enc.params['conv%d/kernel' % i]             # Keras [4,4,4,cin,cout]
+            self._wgrad_conv(eh[i - 1], dcv, self._g('enc/conv%d/kernel' % i), B, 2 * side, cin, cout)
+            wp = self._empty(8, cin, 8 * cout)               # read as a transposed kernel [4,4,4,Cout_T=cin,Cin_T=cout]
+            L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(wp), cout, cin, f32, st)
+            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, cout, cin, f32))
+            dh = self._empty(B, 2 * side, 2 * side, 2 * side, cin)
+            L.call('vv_convT3d_k4s2_fwd', L.ptr(dcv), L.ptr(wp), None, None, L.ptr(dh), B, side, cout, cin, 0, f32, L.ptr(ws), ws.numel(), st)
+            side *= 2
+        dcv = self._bn_bwd(ec[0], dh, ebn[0], B * side ** 3, 'enc/bn0/gamma', 'enc/bn0/beta', act)
+        self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0])
+
+        if self.debug is not None:
+            self.debug.update({'dlogit': dlogit, 'probs': probs, 'enc_out': enc_out, 'z': z, 'dz': dz, 'de': de, 'c_d0': c_d0,
+                               't0': t0, 'dt0': dt0, 'h_dec': dh_, 'c_dec': dc_, 'h_enc': eh, 'c_enc': ec})
+
+        # ---------------- cross-rank gradient sum, then Adam on every replica
+        self.grads.all_reduce(self.group)
+        self.t += 1
+        lr_t = self.lr * (1.0 - ADAM_B2 ** self.t) ** 0.5 / (1.0 - ADAM_B1 ** self.t)
+        for name, _ in self.order:
+            p = self._p(name)
+            L.call('vv_adam_step', L.ptr(p), L.ptr(self._g(name)), L.ptr(self.m[name]), L.ptr(self.v[name]), p.numel(), lr_t,
+                   ADAM_B1, ADAM_B2, ADAM_EPS, st)
+        enc._dirty = True
+        dec._dirty = True
+        return kl, stats, metrics

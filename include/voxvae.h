@@ -152,6 +152,57 @@ int vv_kl_loss(const float *mean, const float *logvar, const float *mean_target,
 /* sampling(mu, logVar) = mu + sqrt(exp(logVar))*eps, eps injected  (function.py:35-38). */
 int vv_sampling(const float *mu, const float *logvar, const float *eps, float *out, long n, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Training path (nolboSingleObject_modelnet_category_{VAE,AE}.fit, nolbo.py:1411-1447 / 1230-1258).  float32.
+ * Data gradients reuse the forward kernels: d(Conv3D k4 s2)/d(input) = vv_convT3d_k4s2_fwd with the SAME Keras
+ * kernel array packed by vv_pack_convT_k4s2 (read as [4,4,4,Cout_T = Cin, Cin_T = Cout]); d(Conv3DTranspose k4 s2)/
+ * d(input) = vv_conv3d_k4s2_fwd with vv_pack_conv_k4 of the same array; Dense: vv_dense_fwd with the Keras
+ * [in,out] array as the [N][K] panel. */
+
+/* BatchNormalization(training=True) statistics over x[rows][channels] (autoencoder3D.py:31,46,62): batch mean,
+ * biased variance, rstd = 1/sqrt(var+eps), folded scale = gamma*rstd, shift = beta - mean*scale; moving statistics
+ * updated in place with `momentum` (Keras 0.99) when the pointers are non-NULL. */
+size_t vv_bn_workspace_bytes(long rows, int channels);
+int vv_bn_train_stats(const float *x, long rows, int channels, const float *gamma, const float *beta, float eps,
+                      float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
+                      float *moving_mean, float *moving_var, void *workspace, size_t workspace_bytes, void *stream);
+/* y = act(x*scale + shift) */
+int vv_bn_act_fwd(const float *x, const float *scale, const float *shift, float *y, long rows, int channels, int act,
+                  void *stream);
+/* Backward of act(BN(x)): given dy = dL/dy, writes dgamma, dbeta [channels] and dx = dL/dx [rows][channels]. */
+int vv_bn_act_bwd(const float *x, const float *dy, const float *scale, const float *shift, const float *mean,
+                  const float *rstd, float *dgamma, float *dbeta, float *dx, long rows, int channels, int act,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Weight gradients as reduction-over-rows GEMMs on the exact-f32 MFMA: dw[m][n] = sum_r a[r][m] * g[r][n]. */
+size_t vv_wgrad_workspace_bytes(long rows, int m, int n);
+int vv_wgrad_dense(const float *a, const float *g, float *dw, long rows, int m, int n, int lda, void *workspace,
+                   size_t workspace_bytes, void *stream);
+/* a[r][(t,ci)] = src[b, 2o-1+t, ci] gathered over the half-size grid (zero in the SAME padding); g [B*(side/2)^3][cout].
+ * Conv3D k4 s2 (src = layer input, g = dL/d(conv out)): dw = Keras [4,4,4,cin,cout].  Conv3DTranspose k4 s2 (src =
+ * dL/d(out) on the big grid, g = layer input): dw = Keras [4,4,4,Cout,Cin] with (cin, cout) := (Cout, Cin).
+ * cin == 1 (first conv / last transposed conv) or cin % 64 == 0. */
+int vv_wgrad_conv_k4s2(const float *src, const float *g, float *dw, int batch, int side, int cin, int cout,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* Adjoints of vv_pack_conv_k4s1_meanpool / vv_pack_convT_k4s1_dense: panel gradient -> Keras kernel gradient. */
+int vv_unpack_meanpool_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream);
+int vv_unpack_convT_dense_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream);
+/* out[cols][rows] = in[rows][cols]^T (panel transposes for the dense-panel data gradients). */
+int vv_transpose_f32(const float *in, float *out, int rows, int cols, void *stream);
+/* out[c] = sum_r x[r][c] (Dense bias gradient). */
+int vv_colsum(const float *x, float *out, long rows, int cols, void *stream);
+
+/* dlogit = d(mean_b binary_loss_b)/dlogit through sigmoid and the epsilon clip (function.py:73-82). */
+int vv_bce_bwd(const float *probs, const float *target, float *dlogit, int batch, long voxels, float gamma, float epsilon,
+               float inv_batch, void *stream);
+/* Backward of vv_reparam_kl_fwd for total = mean_b KL + ...: d_enc_out [B,2L] from dz [B,L]. */
+int vv_reparam_kl_bwd(const float *enc_out, const float *eps, const float *dz, const float *drop_mask, float drop_scale,
+                      float *d_enc_out, int batch, int latent, float inv_batch, void *stream);
+/* Keras Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; param -= lr_t m / (sqrt(v) + eps),
+ * lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller (nolbo.py:1402, 1441). */
+int vv_adam_step(float *param, const float *grad, float *m, float *v, long n, float lr_t, float beta1, float beta2,
+                 float epsilon, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

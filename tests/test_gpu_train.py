@@ -1,0 +1,81 @@
+"""GPU parity of one training step (fit) against the torch-CPU float64 autograd oracle: losses, every gradient,
+the Adam-updated weights and the BatchNorm moving statistics.  f32 (exact-f32 MFMA) mode."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _setup(D, Lz, var, B, seed=0):
+    import voxvae
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('f32')
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(D, Lz, var)
+    ep = syn.make_encoder_params(cfg['encoder'], seed=42, nontrivial_affine=True)
+    dp = syn.make_decoder_params(cfg['decoder'], seed=43, nontrivial_affine=True, final_gain=2.0)   # keep logits away from the clip's gradient discontinuity at |l| ~ 16
+    cls = nolbo.nolboSingleObject_modelnet_category_VAE if var else nolbo.nolboSingleObject_modelnet_category_AE
+    model = cls(nolbo_structure=cfg, learning_rate=1e-3)
+    model._encoder.set_weights_dict(ep)
+    model._decoder.set_weights_dict(dp)
+    x = syn.make_voxels(B, D, seed=100 + seed)
+    eps = syn.make_eps(B, Lz, seed=200 + seed)
+    return cfg, ep, dp, model, x, eps
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize('D,Lz,var,B', [(32, 64, True, 4), (16, 64, True, 6), (32, 64, False, 3)])
+def test_fit_step_matches_autograd_oracle(D, Lz, var, B):
+    from oracle import torch_oracle as to
+    cfg, ep, dp, model, x, eps = _setup(D, Lz, var, B)
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=var)
+    out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
+    torch.cuda.synchronize()
+    vals = [float(v) for v in out]
+    if var:
+        assert abs(vals[0] - ref['loss_kl']) <= 1e-4 * max(1.0, abs(ref['loss_kl']))
+        vals = vals[1:]
+    assert abs(vals[0] - ref['loss_shape']) <= 2e-4 * abs(ref['loss_shape'])
+    assert abs(vals[1] - ref['pr']) < 1e-3 and abs(vals[2] - ref['rc']) < 1e-3
+    tr = model._trainer
+    worst = {}
+    for name in ref['grads']:
+        g = tr.grads.views[name].cpu().numpy()
+        if name == 'dec/dense/bias':        # a bias in front of BatchNorm has zero gradient: compare absolutely
+            assert np.abs(g).max() < 1e-5 and np.abs(ref['grads'][name]).max() < 1e-9
+            continue
+        worst[name] = _rel(g, ref['grads'][name])
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, 'gradient mismatch (max rel err): %s' % bad
+    new_e, new_d = model._encoder.get_weights_dict(), model._decoder.get_weights_dict()
+    for k, v in list(new_e.items()) + list(new_d.items()):
+        key = ('enc/' if k in new_e and v is new_e.get(k) else 'dec/') + k
+        r = ref['params'][key]
+        if k.endswith(('moving_mean', 'moving_variance')):
+            np.testing.assert_allclose(v, r, rtol=1e-4, atol=1e-6, err_msg=key)
+        else:
+            # Adam's first step moves every weight by ~lr * sign(g): compare the step, tolerant where |g| ~ 0
+            old = (ep if key.startswith('enc/') else dp)[k]
+            step_ref, step_got = r - old, v - old
+            g = ref['grads'][key]
+            if key == 'dec/dense/bias':
+                continue
+            big = np.abs(g) > 1e-3 * np.abs(g).max()
+            assert np.abs(step_got - step_ref)[big].max() <= 0.02 * 1e-3 + 1e-9, key
+    print('\n[fit D%d L%d var%d B%d] worst grad rel err %.2e (%s)' % (D, Lz, var, B, max(worst.values()), max(worst, key=worst.get)))
+
+
+def test_two_steps_loss_decreases_and_state_advances():
+    cfg, ep, dp, model, x, eps = _setup(32, 64, True, 8, seed=3)
+    l0 = [float(v) for v in model.fit((x, x), _eps=eps)]
+    for _ in range(5):
+        l1 = [float(v) for v in model.fit((x, x), _eps=eps)]
+    assert model._trainer.t == 6
+    assert l1[1] < l0[1], (l0, l1)          # same batch, 6 Adam steps at lr 1e-3: the shape loss must go down
+    assert all(np.isfinite(l1))
