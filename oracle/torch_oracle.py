@@ -95,7 +95,7 @@ def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_s
     l32 = logits.detach().to(torch.float32)
     p32 = 1.0 / (1.0 + torch.exp(-l32))            # the reference's float32 sigmoid, evaluated in float32
     inside = (p32 >= torch.tensor(1e-7, dtype=torch.float32)) & (p32 <= torch.tensor(1.0, dtype=torch.float32) - torch.tensor(1e-7, dtype=torch.float32))
-    q = torch.where(inside, p, torch.clamp(p.detach(), 1e-7, 1.0 - 1e-7))
+    q = torch.clamp(p, 1e-7, 1.0 - 1e-7).detach() + (p - p.detach()) * inside.to(p.dtype)   # clipped value, masked gradient
     B = x.shape[0]
     bce = -(0.6 * y * torch.log(q) + 0.4 * (1.0 - y) * torch.log(1.0 - q)).reshape(B, -1).sum(-1)
     return kl, bce.mean(), p, stats
@@ -140,6 +140,6 @@ def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variatio
     tp = (yn * yh).reshape(B, -1).sum(-1)
     fp = ((1 - yn) * yh).reshape(B, -1).sum(-1)
     fn = (yn * (1 - yh)).reshape(B, -1).sum(-1)
-    return {'loss_kl': float(kl), 'loss_shape': float(shape), 'pr': float(np.mean(tp / (tp + fp + 1e-10))),
+    return {'loss_kl': float(kl.detach()), 'loss_shape': float(shape.detach()), 'pr': float(np.mean(tp / (tp + fp + 1e-10))),
             'rc': float(np.mean(tp / (tp + fn + 1e-10))), 'grads': g, 'params': new, 'bn_stats': stats,
             'adam': {'t': t, 'm': m2, 'v': v2}, 'probs': pn}
