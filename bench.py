@@ -97,12 +97,15 @@ def main():
     lm = {n: v for n, v, _ in workload.layer_macs(cfg)}
     dominant, breakdown = 'D4', None
     if not a.no_breakdown:
-        t = E.LayerTimer()
-        model._enc_eng.timer = model._dec_eng.timer = t
-        for _ in range(5):
+        for _ in range(3):                      # weight packing, allocator growth and clock ramp happen here
             step()
         torch.cuda.synchronize()
-        breakdown = {k: round(v[1], 4) for k, v in t.summary_ms().items()}
+        t = E.LayerTimer()
+        model._enc_eng.timer = model._dec_eng.timer = t
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        breakdown = {k: round(float(np.median([e0.elapsed_time(e1) for e0, e1 in v])), 4) for k, v in t.events.items()}
         dominant = max(breakdown, key=breakdown.get)
     tm = E.LayerTimer(only=dominant)
     model._enc_eng.timer = model._dec_eng.timer = tm
