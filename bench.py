@@ -148,6 +148,11 @@ def main():
         logit_err = float(np.abs(lg.cpu().numpy() - ref['logits']).max())
 
 
+    traffic = None
+    tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')   # rocprofv3 PMC passes (cannot be collected live)
+    if os.path.exists(tf) and a.dtype == 'bf16' and a.batch == 256 and a.voxel == 32:
+        traffic = json.load(open(tf))['layers'].get(dominant, {}).get('hbm_bytes_per_launch')
+
     if rank == 0:
         flops = 2.0 * lm[dominant] * a.batch                     # algorithmic (valid-tap) FLOPs of one launch
         achieved = flops / (kms * 1e-3)
@@ -169,7 +174,7 @@ def main():
                            'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},
             'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel (%s, layer %s)' % (a.dtype, dominant),
                          'achieved': achieved / 1e12, 'peak': PEAK[a.dtype] / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK[a.dtype], 'traffic': None,
+                         'frac': achieved / PEAK[a.dtype], 'traffic': traffic,
                          'launch_ms': kms, 'launches_timed': nl, 'algorithmic_flops_per_launch': flops},
             'layer_ms': breakdown,
             'cpu_baseline': cpu,
