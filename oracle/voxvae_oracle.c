@@ -30,41 +30,39 @@ VVO_API int vvo_num_threads(void) { return omp_get_max_threads(); }
 
 /* Conv3D(padding='same', use_bias=False): src/net_core/autoencoder3D.py:27-30, 86-88.
  * x [B,D,D,D,Ci]; w [k,k,k,Ci,Co] (Keras kernel layout); y [B,O,O,O,Co], O = ceil(D/s).
- * y[o,co] = sum_{t,ci} x[s*o - pb + t, ci] * w[t,ci,co]   (taps that fall in the padding skipped). */
+ * y[o,co] = sum_{t,ci} x[s*o - pb + t, ci] * w[t,ci,co]   (taps that fall in the padding skipped).
+ * One (b, od, oh) row of outputs is accumulated at a time so each weight row w[t,ci,:] is reused across the row. */
 VVO_API void vvo_conv3d_same(const float *x, const float *w, float *y, int B, int D, int Ci, int Co, int k, int s) {
     int O, pb;
     same_pad(D, k, s, &O, &pb);
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int b = 0; b < B; ++b)
-        for (int od = 0; od < O; ++od) {
-            float *acc = (float *)malloc(sizeof(float) * Co);
-            for (int oh = 0; oh < O; ++oh)
-                for (int ow = 0; ow < O; ++ow) {
-                    for (int c = 0; c < Co; ++c) acc[c] = 0.f;
-                    for (int td = 0; td < k; ++td) {
-                        int id = s * od - pb + td;
-                        if (id < 0 || id >= D) continue;
-                        for (int th = 0; th < k; ++th) {
-                            int ih = s * oh - pb + th;
-                            if (ih < 0 || ih >= D) continue;
-                            for (int tw = 0; tw < k; ++tw) {
-                                int iw = s * ow - pb + tw;
-                                if (iw < 0 || iw >= D) continue;
-                                const float *xp = x + ((((size_t)b * D + id) * D + ih) * D + iw) * Ci;
-                                const float *wp = w + (size_t)((td * k + th) * k + tw) * Ci * Co;
-                                for (int ci = 0; ci < Ci; ++ci) {
-                                    float a = xp[ci];
-                                    const float *wr = wp + (size_t)ci * Co;
-                                    for (int c = 0; c < Co; ++c) acc[c] += a * wr[c];
+        for (int od = 0; od < O; ++od)
+            for (int oh = 0; oh < O; ++oh) {
+                float *acc = y + (((size_t)b * O + od) * O + oh) * O * Co; /* [O][Co] row block of the output */
+                for (size_t i = 0; i < (size_t)O * Co; ++i) acc[i] = 0.f;
+                for (int td = 0; td < k; ++td) {
+                    int id = s * od - pb + td;
+                    if (id < 0 || id >= D) continue;
+                    for (int th = 0; th < k; ++th) {
+                        int ih = s * oh - pb + th;
+                        if (ih < 0 || ih >= D) continue;
+                        for (int tw = 0; tw < k; ++tw) {
+                            const float *wp = w + (size_t)((td * k + th) * k + tw) * Ci * Co;
+                            for (int ci = 0; ci < Ci; ++ci) {
+                                const float *wr = wp + (size_t)ci * Co;
+                                for (int ow = 0; ow < O; ++ow) {
+                                    int iw = s * ow - pb + tw;
+                                    if (iw < 0 || iw >= D) continue;
+                                    float a = x[((((size_t)b * D + id) * D + ih) * D + iw) * Ci + ci];
+                                    float *ar = acc + (size_t)ow * Co;
+                                    for (int c = 0; c < Co; ++c) ar[c] += a * wr[c];
                                 }
                             }
                         }
                     }
-                    float *yp = y + ((((size_t)b * O + od) * O + oh) * O + ow) * Co;
-                    for (int c = 0; c < Co; ++c) yp[c] = acc[c];
                 }
-            free(acc);
-        }
+            }
 }
 
 /* Conv3DTranspose(padding='same', use_bias=False): autoencoder3D.py:42-45, 129-132.
@@ -79,51 +77,55 @@ VVO_API void vvo_conv3d_transpose_same(const float *x, const float *w, float *y,
     for (int t = 0; t < k * k * k; ++t)
         for (int co = 0; co < Co; ++co)
             for (int ci = 0; ci < Ci; ++ci) wt[((size_t)t * Ci + ci) * Co + co] = w[((size_t)t * Co + co) * Ci + ci];
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(3) schedule(static)
     for (int b = 0; b < B; ++b)
-        for (int od = 0; od < N; ++od) {
-            float *acc = (float *)malloc(sizeof(float) * Co);
-            for (int oh = 0; oh < N; ++oh)
-                for (int ow = 0; ow < N; ++ow) {
-                    for (int c = 0; c < Co; ++c) acc[c] = 0.f;
-                    for (int td = 0; td < k; ++td) {
-                        int nd = od + pb - td;
-                        if (nd < 0 || nd % s) continue;
-                        int id = nd / s;
-                        if (id >= D) continue;
-                        for (int th = 0; th < k; ++th) {
-                            int nh = oh + pb - th;
-                            if (nh < 0 || nh % s) continue;
-                            int ih = nh / s;
-                            if (ih >= D) continue;
-                            for (int tw = 0; tw < k; ++tw) {
-                                int nw = ow + pb - tw;
-                                if (nw < 0 || nw % s) continue;
-                                int iw = nw / s;
-                                if (iw >= D) continue;
-                                const float *xp = x + ((((size_t)b * D + id) * D + ih) * D + iw) * Ci;
-                                int t = (td * k + th) * k + tw;
-                                if (Co == 1) {
-                                    const float *wr = w + (size_t)t * Ci;
+        for (int od = 0; od < N; ++od)
+            for (int oh = 0; oh < N; ++oh) {
+                float *acc = y + (((size_t)b * N + od) * N + oh) * N * Co; /* [N][Co] row block */
+                for (size_t i = 0; i < (size_t)N * Co; ++i) acc[i] = 0.f;
+                for (int td = 0; td < k; ++td) {
+                    int nd = od + pb - td;
+                    if (nd < 0 || nd % s) continue;
+                    int id = nd / s;
+                    if (id >= D) continue;
+                    for (int th = 0; th < k; ++th) {
+                        int nh = oh + pb - th;
+                        if (nh < 0 || nh % s) continue;
+                        int ih = nh / s;
+                        if (ih >= D) continue;
+                        for (int tw = 0; tw < k; ++tw) {
+                            int t = (td * k + th) * k + tw;
+                            if (Co == 1) {
+                                const float *wr = w + (size_t)t * Ci;
+                                for (int ow = 0; ow < N; ++ow) {
+                                    int nw = ow + pb - tw;
+                                    if (nw < 0 || nw % s) continue;
+                                    int iw = nw / s;
+                                    if (iw >= D) continue;
+                                    const float *xp = x + ((((size_t)b * D + id) * D + ih) * D + iw) * Ci;
                                     float d = 0.f;
                                     for (int ci = 0; ci < Ci; ++ci) d += xp[ci] * wr[ci];
-                                    acc[0] += d;
-                                } else {
-                                    const float *wp = wt + (size_t)t * Ci * Co;
-                                    for (int ci = 0; ci < Ci; ++ci) {
-                                        float a = xp[ci];
-                                        const float *wr = wp + (size_t)ci * Co;
-                                        for (int c = 0; c < Co; ++c) acc[c] += a * wr[c];
+                                    acc[ow] += d;
+                                }
+                            } else {
+                                const float *wp = wt + (size_t)t * Ci * Co;
+                                for (int ci = 0; ci < Ci; ++ci) {
+                                    const float *wr = wp + (size_t)ci * Co;
+                                    for (int ow = 0; ow < N; ++ow) {
+                                        int nw = ow + pb - tw;
+                                        if (nw < 0 || nw % s) continue;
+                                        int iw = nw / s;
+                                        if (iw >= D) continue;
+                                        float a = x[((((size_t)b * D + id) * D + ih) * D + iw) * Ci + ci];
+                                        float *ar = acc + (size_t)ow * Co;
+                                        for (int c = 0; c < Co; ++c) ar[c] += a * wr[c];
                                     }
                                 }
                             }
                         }
                     }
-                    float *yp = y + ((((size_t)b * N + od) * N + oh) * N + ow) * Co;
-                    for (int c = 0; c < Co; ++c) yp[c] = acc[c];
                 }
-            free(acc);
-        }
+            }
     free(wt);
 }
 
