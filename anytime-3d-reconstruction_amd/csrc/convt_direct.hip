@@ -1,0 +1,274 @@
+// Direct transposed convolution on MFMA with the input tile resident in LDS (bf16, gfx950).
+//
+// Conv3DTranspose k4 s2 SAME (autoencoder3D.py:41-54) as 8 output-parity sub-convolutions reads every input voxel
+// 64 times (8 parities x 8 taps).  The implicit-GEMM kernel re-fetches those rows from L2 for every (parity, tap) and
+// is bound by L2 -> CU bytes (96 B/clk/CU at full MFMA rate for a 128 x 64 tile).  Here one workgroup stages the
+// (4+2) x (4+2) x (8+2) halo tile of its 4 x 4 x 8 block of input cells ONCE (LDS-DMA, zeros outside the grid), and all
+// 8 parities x 8 taps read their A fragments from it; the weights are streamed straight into registers from a
+// fragment-ordered panel (one fully coalesced 1 KiB load per MFMA operand, each byte used once per workgroup).
+//
+//   LDS tile   : 360 voxels x CIN bf16, 16-byte slots XOR-swizzled with (zw + 8 zh) & 15 -- conflict-free for every
+//                tap and both ds_read_b128 lane groups (exhaustively checked offline)
+//   waves      : 4; wave w owns parities 2w, 2w+1 (one after the other): 4 row tiles (md = 0..3, 32 cells each)
+//                x COUT/32 channel tiles of 32x32 accumulators; weights-first MFMA, lane = cell, registers walk channels
+//   epilogue   : folded BN + activation on float4 quads, wave-private LDS transpose, 16-byte stores of whole channel rows
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// out[p][a][ks][nt][lane][j] = w[t(p,a)][co = nt*32 + (lane&31)][ci = ks*16 + 8*(lane>>5) + j]
+__global__ void pack_convT_frag_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    const int KS = cin / 16, NT = cout / 32;
+    const long total = (long)8 * 8 * KS * NT * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        long r = i >> 9;
+        const int nt = (int)(r % NT); r /= NT;
+        const int ks = (int)(r % KS); r /= KS;
+        const int a = (int)(r & 7), p = (int)(r >> 3);
+        const int td = 1 - ((p >> 2) & 1) + 2 * ((a >> 2) & 1);
+        const int th = 1 - ((p >> 1) & 1) + 2 * ((a >> 1) & 1);
+        const int tw = 1 - (p & 1) + 2 * (a & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        const int co = nt * 32 + (lane & 31), ci = ks * 16 + 8 * (lane >> 5) + j;
+        out[i] = static_cast<__bf16>(w[((size_t)t * cout + co) * cin + ci]);
+    }
+}
+
+constexpr int HH = 6, HW = 10;   // halo tile of an MT x 4 x 8 block of cells: (MT+2) x 6 x 10 voxels
+
+template <int CIN, int COUT, int MT>
+__global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wf,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              __bf16 *__restrict__ y, int din_log2, unsigned x_bytes, int act) {
+    constexpr int RB = CIN * 2;          // bytes per voxel row
+    constexpr int SPR = RB / 16;         // 16-byte slots per row (16 for CIN = 128)
+    constexpr int KS = CIN / 16;         // MFMA k-steps per tap
+    constexpr int NT = COUT / 32;        // channel tiles
+    constexpr int HALF = MT == 4 ? KS / 2 : 2;   // k-steps per weight prefetch group (register budget: 2 waves/SIMD at MT 2)
+    constexpr int GPT = KS / HALF;       // groups per tap
+    constexpr int GPP = 8 * GPT;         // groups per parity
+    constexpr int SPITCH = COUT * 2 + 16;
+    constexpr int HV = (MT + 2) * HH * HW;
+    static_assert(SPR == 16, "the slot swizzle is derived for 256-byte voxel rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *tile = smem;                                   // [360][RB]
+    char *stage = smem + HV * RB;                        // [4 waves][32][SPITCH]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = din_log2, n = 1 << li;
+    const int bxw = n >> 3, bxh = n >> 2, bxd = n / MT;  // boxes along w / h / d
+    int blk = blockIdx.x;
+    const int bw = blk % bxw; blk /= bxw;
+    const int bh = blk % bxh; blk /= bxh;
+    const int bd = blk % bxd; const int b = blk / bxd;
+    const int d0 = bd * MT, h0 = bh * 4, w0 = bw * 8;
+
+    // ---- stage the halo tile: 360 voxels x 16 slots = 90 wave instructions of 1 KiB (4 voxels each)
+    {
+        const u32x4 rs = make_rsrc(x, x_bytes);
+        const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)tile;
+        const int pos = lane & 15, vsub = lane >> 4;
+        for (int it = wave; it < HV / 4; it += 4) {
+            const int v = it * 4 + vsub;
+            const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
+            const int id = d0 - 1 + zd, ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+            const bool ok = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+            const int g = pos ^ ((zw + 8 * zh) & 15);
+            const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * RB + g * 16 : 0xFFFFFFF0u;
+            dma16(rs, vo, lds0 + it * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int mh = fr >> 3, mw = fr & 7;
+    const uint4 *wfl = reinterpret_cast<const uint4 *>(wf) + lane;      // + ((((p*8 + a)*KS + ks)*NT + nt) * 64)
+    char *mystage = stage + wave * 32 * SPITCH;
+    const int lo = li + 1;
+
+    // Weights: this wave's 2 parities x 16 half-tap groups are 32 consecutive groups of the fragment panel.  They are
+    // streamed through a 4-deep register ring (3 groups = 96 MFMAs ~ 3 k cycles of prefetch distance: with one wave per
+    // SIMD nothing else hides the L2 latency), running ahead across the parity boundary and its epilogue.
+    constexpr int GL = HALF * NT;                          // 16-byte loads per lane per group
+    const uint4 *wp = wfl + (size_t)(wave * 2 * GPP) * GL * 64;
+    uint4 b0[GL], b1[GL], b2[GL], b3[GL];
+    auto load_group = [&](int G, uint4 *dst) {
+        if (G < 2 * GPP) {
+            const uint4 *src = wp + (size_t)G * GL * 64;
+#pragma unroll
+            for (int i = 0; i < GL; ++i) dst[i] = src[(size_t)i * 64];
+        }
+    };
+    load_group(0, b0);
+    load_group(1, b1);
+    load_group(2, b2);
+
+    auto run_parity = [&](auto act_c, int pi) {
+        constexpr int ACT = decltype(act_c)::value;
+        const int p = wave * 2 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
+
+        auto compute_group = [&](int g, const uint4 *bf) {   // g = tap*GPT + part
+            const int a = g / GPT, ad = (a >> 2) & 1, ah = (a >> 1) & 1, aw = a & 1;
+            const int zh = mh + ph - ah + 1, zw = mw + pw - aw + 1;
+            const int sw = (zw + 8 * zh) & 15;
+            const char *vrow = tile + (((pd - ad + 1) * HH + zh) * HW + zw) * RB;   // + md * HH * HW * RB per row tile
+            uint4 fa[2][MT];
+            auto read_a = [&](int k, uint4 *dst) {
+                const int slot = ((((g % GPT) * HALF + k) * 2 + fh) ^ sw) * 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const uint4 *>(vrow + mt * (HH * HW * RB) + slot);
+            };
+            read_a(0, fa[0]);
+#pragma unroll
+            for (int k = 0; k < HALF; ++k) {
+                if (k + 1 < HALF) read_a(k + 1, fa[(k + 1) & 1]);       // one k-step ahead of the MFMAs that use it
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&bf[k * NT + nt]),
+                                                                              *reinterpret_cast<const bf16x8 *>(&fa[k & 1][mt]), acc[mt][nt], 0, 0, 0);
+            }
+        };
+#pragma unroll 1
+        for (int g = 0; g < GPP; g += 4) {
+            const int G = pi * GPP + g;
+            load_group(G + 3, b3); compute_group(g, b0);
+            load_group(G + 4, b0); compute_group(g + 1, b1);
+            load_group(G + 5, b1); compute_group(g + 2, b2);
+            load_group(G + 6, b2); compute_group(g + 3, b3);
+        }
+
+        // ---- epilogue of this parity: lane = cell (mt, mh, mw), registers walk channels
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nt * 32 + 8 * g + 4 * fh;
+                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c);
+                    if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c);
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
+                        if (ACT == VV_ACT_ELU) t = t > 0.f ? t : __expf(t) - 1.f;
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        o[e] = static_cast<__bf16>(t);
+                    }
+                    *reinterpret_cast<bf16x4 *>(mystage + fr * SPITCH + c * 2) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int CPR = COUT * 2 / 16;            // 16-byte chunks per output row
+#pragma unroll
+            for (int i = 0; i < 32 * CPR / 64; ++i) {
+                const int id = lane + 64 * i, r = id / CPR, c = id % CPR;
+                const int od = 2 * (d0 + mt) + pd, oh = 2 * (h0 + (r >> 3)) + ph, ow = 2 * (w0 + (r & 7)) + pw;
+                const size_t vox = (((((size_t)b << lo) + od) << lo) + oh << lo) + ow;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (COUT * 2) + c * 16) =
+                    *reinterpret_cast<const uint4 *>(mystage + r * SPITCH + c * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+#pragma unroll 1
+    for (int pi = 0; pi < 2; ++pi) {
+        switch (act) {
+            case VV_ACT_ELU: run_parity(std::integral_constant<int, VV_ACT_ELU>{}, pi); break;
+            case VV_ACT_RELU: run_parity(std::integral_constant<int, VV_ACT_RELU>{}, pi); break;
+            case VV_ACT_LRELU: run_parity(std::integral_constant<int, VV_ACT_LRELU>{}, pi); break;
+            default: run_parity(std::integral_constant<int, VV_ACT_NONE>{}, pi); break;
+        }
+    }
+}
+
+inline int grid_1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+VV_EXPORT int vv_convT3d_k4s2_direct_supported(int side, int cin, int cout, int dtype) {
+    return dtype == VV_BF16 && cin == 128 && cout == 64 && side >= 8 && vv_is_pow2(side);
+}
+
+VV_EXPORT int vv_pack_convT_k4s2_frag(const float *w_keras, void *packed, int cin, int cout, void *stream) {
+    if (!w_keras || !packed) return VV_ERR_NULL;
+    if (cin <= 0 || cout <= 0 || cin % 16 || cout % 32) return VV_ERR_SHAPE;
+    VV_LAUNCH(pack_convT_frag_kernel, dim3(grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+              reinterpret_cast<__bf16 *>(packed), cin, cout);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
+                                         int batch, int side, int cin, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_frag || !y) return VV_ERR_NULL;
+    if (!vv_convT3d_k4s2_direct_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_frag) || !vv_aligned16(y)) return VV_ERR_ALIGN;
+    const size_t xb = (size_t)batch * side * side * side * cin * 2;
+    if (xb >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
+    static const int mt_sel = getenv("VV_DIRECT_MT") ? atoi(getenv("VV_DIRECT_MT")) : 2;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mt_sel == 4) {
+        const int boxes = (side / 4) * (side / 4) * (side / 8);
+        const size_t lds = (size_t)6 * HH * HW * cin * 2 + 4 * 32 * (cout * 2 + 16);
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_kernel<128, 64, 4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 6 * HH * HW * 128 * 2 + 4 * 32 * (64 * 2 + 16));
+            return true;
+        }();
+        (void)attr;
+        VV_LAUNCH((convT_direct_kernel<128, 64, 4>), dim3(batch * boxes), dim3(256), lds, st, reinterpret_cast<const __bf16 *>(x),
+                  reinterpret_cast<const __bf16 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y), vv_log2(side), (unsigned)xb, act);
+    } else {
+        const int boxes = (side / 2) * (side / 4) * (side / 8);
+        const size_t lds = (size_t)4 * HH * HW * cin * 2 + 4 * 32 * (cout * 2 + 16);
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_kernel<128, 64, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HH * HW * 128 * 2 + 4 * 32 * (64 * 2 + 16));
+            return true;
+        }();
+        (void)attr;
+        VV_LAUNCH((convT_direct_kernel<128, 64, 2>), dim3(batch * boxes), dim3(256), lds, st, reinterpret_cast<const __bf16 *>(x),
+                  reinterpret_cast<const __bf16 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y), vv_log2(side), (unsigned)xb, act);
+    }
+    return vv_launch_status();
+}

@@ -6,6 +6,7 @@ tensors), the packed MFMA panels derived from them and the layer chain, and driv
 arithmetic step is a libvoxvae kernel.  Reference: src/net_core/autoencoder3D.py:72-139.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -253,6 +254,10 @@ class DecoderEngine(_EngineBase):
             pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1])
             L.call('vv_pack_convT_k4s2', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['w%d' % i]), f[i - 1], f[i], self.dt, st)
             pk['scale%d' % i], pk['shift%d' % i] = self._fold('bnT%d' % i, f[i])
+            side_i = self.S << (i - 1)
+            if not os.environ.get('VV_NO_DIRECT') and L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt):
+                pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
+                L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
 
     def forward(self, z_act, target=None, want_logits=False, gamma=0.6, epsilon=1e-7):
         """z_act: [B,L] in the activation dtype.  target: float32 [B,D,D,D,1] or None.
@@ -276,6 +281,11 @@ class DecoderEngine(_EngineBase):
         for i in range(1, len(f) - 1):
             ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))
             o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+            if ('wf%d' % i) in pk:
+                self._call('D%d' % (i + 1), 'vv_convT3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['wf%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                h, side = o, 2 * side
+                continue
             self._call('D%d' % (i + 1), 'vv_convT3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
                    L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
             h, side = o, 2 * side

@@ -158,9 +158,30 @@ def main():
         traffic = json.load(open(tf))['layers'].get(dominant, {}).get('hbm_bytes_per_launch')
 
     if rank == 0:
-        flops = 2.0 * lm[dominant] * a.batch                     # algorithmic (valid-tap) FLOPs of one launch
-        achieved = flops / (kms * 1e-3)
         fl_rec, fl_dense = workload.flops_per_reconstruction(cfg)
+        flops = 2.0 * lm[dominant] * a.batch                     # algorithmic (valid-tap) FLOPs of one launch
+        es = 2 if a.dtype == 'bf16' else 4
+        nlast = len(cfg['decoder']['filter_num_list'])
+        half = (a.voxel // 2) ** 3
+        if dominant == 'D%d' % nlast:        # decoder tail + losses: reads the widest activation + target, writes probabilities
+            abytes = a.batch * (half * cfg['decoder']['filter_num_list'][-2] * es + 2 * a.voxel ** 3 * 4)
+            roof = {'bound': 'hbm', 'kernel': 'final_bce kernel (%s, layer %s)' % (a.dtype, dominant), 'achieved': abytes / (kms * 1e-3) / 1e9,
+                    'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (kms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
+        elif dominant == 'E1':               # first conv: reads the f32 occupancy grid, writes the widest encoder activation
+            abytes = a.batch * (a.voxel ** 3 * 4 + half * cfg['encoder']['filter_num_list'][0] * es)
+            roof = {'bound': 'hbm', 'kernel': 'igemm_kernel MODE_FIRST (%s, layer E1)' % a.dtype, 'achieved': abytes / (kms * 1e-3) / 1e9,
+                    'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (kms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
+        else:
+            achieved = flops / (kms * 1e-3)
+            roof = {'bound': 'mfma', 'kernel': 'conv kernel (%s, layer %s)' % (a.dtype, dominant), 'achieved': achieved / 1e12,
+                    'peak': PEAK[a.dtype] / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / PEAK[a.dtype], 'algorithmic_flops_per_launch': flops}
+        roof.update({'traffic': traffic, 'launch_ms': kms, 'launches_timed': nl})
+        # the heaviest MFMA layer as well, whatever is dominant
+        mf = max((k for k in (breakdown or {}) if k not in ('E1', 'D%d' % nlast)), key=lambda k: (breakdown or {}).get(k, 0), default=None)
+        mfma_layer = None
+        if mf is not None:
+            mfma_layer = {'layer': mf, 'ms': breakdown[mf], 'TFLOPs': 2.0 * lm[mf] * a.batch / (breakdown[mf] * 1e-3) / 1e12,
+                          'frac_of_mfma_peak': 2.0 * lm[mf] * a.batch / (breakdown[mf] * 1e-3) / PEAK[a.dtype]}
         out = {
             'metric': '32^3 voxel reconstructions/sec at batch=256; IoU delta vs reference',
             'value': world * a.batch * a.steps / el,
@@ -176,10 +197,8 @@ def main():
             'whole_path': {'algorithmic_flops_per_reconstruction': fl_rec, 'dense_flops_per_reconstruction': fl_dense,
                            'achieved_TFLOPs_per_gpu': fl_rec * a.batch * a.steps / el / 1e12,
                            'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel (%s, layer %s)' % (a.dtype, dominant),
-                         'achieved': achieved / 1e12, 'peak': PEAK[a.dtype] / 1e12, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK[a.dtype], 'traffic': traffic,
-                         'launch_ms': kms, 'launches_timed': nl, 'algorithmic_flops_per_launch': flops},
+            'roofline': roof,
+            'heaviest_mfma_layer': mfma_layer,
             'layer_ms': breakdown,
             'cpu_baseline': cpu,
         }

@@ -87,6 +87,15 @@ int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale,
                         int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* Direct variant of vv_convT3d_k4s2_fwd for the widest decoder layer (bf16, Cin 128 -> Cout 64, side >= 8): the input
+ * halo tile of a 4x4x8 block of cells is staged in LDS once and serves all 8 parities x 8 taps; weights come from the
+ * MFMA-fragment-ordered panel of vv_pack_convT_k4s2_frag ([8 parity][8 tap][Cin/16][Cout/32][64 lanes][8]).
+ * vv_convT3d_k4s2_direct_supported() says whether a shape is covered (callers fall back to vv_convT3d_k4s2_fwd). */
+int vv_convT3d_k4s2_direct_supported(int side, int cin, int cout, int dtype);
+int vv_pack_convT_k4s2_frag(const float *w_keras, void *packed, int cin, int cout, void *stream);
+int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
+                               int batch, int side, int cin, int cout, int act, int dtype, void *stream);
+
 /* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
  * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).
  * out_dtype may differ from dtype (the encoder output is float32). */

@@ -230,3 +230,24 @@ def test_error_codes(L):
     assert lib.vv_dense_fwd(L.ptr(x), L.ptr(x), None, None, L.ptr(x), 2, 64, 8192, 0, 1, 0, None, 0, None) == -5
     with pytest.raises(L.VoxVaeError):
         L.call('vv_shape_metrics', None, None, 1, None)
+
+
+@pytest.mark.parametrize('B,side', [(2, 8), (1, 16), (3, 8)])
+def test_convT3d_k4s2_direct(L, B, side):
+    """LDS-resident input-tile variant of the widest decoder layer (bf16, 128 -> 64)."""
+    cin, cout = 128, 64
+    assert L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, L.VV_BF16) == 1
+    assert L.load().vv_convT3d_k4s2_direct_supported(4, cin, cout, L.VV_BF16) == 0
+    rng = np.random.default_rng(side + B)
+    x = _bf16_round(rng.standard_normal((B, side, side, side, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cout, cin)) / np.sqrt(8 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wf = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_frag', L.ptr(wd), L.ptr(wf), cin, cout, _st())
+    y = torch.full((B, 2 * side, 2 * side, 2 * side, cout), -7.0, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(xd), L.ptr(wf), L.ptr(scd), L.ptr(shd), L.ptr(y), B, side, cin, cout, 1, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'convT3d_k4s2_direct')
