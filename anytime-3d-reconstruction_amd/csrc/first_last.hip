@@ -113,39 +113,57 @@ __global__ __launch_bounds__(256) void final_bce_kernel(const T *__restrict__ x,
 // One workgroup = 4x4x4 input cells (+1 halo: 216 rows, padded to 224) -> P in LDS (f32, aliased over the
 // staged operands) -> every lane gathers its 2 x 8 terms, then sigmoid / BCE / TP / FP / FN as in the VALU kernel.
 constexpr int FM_ROWS = 224;            // 216 halo voxels padded to 7 MFMA row tiles
-constexpr int FM_PPITCH = 65;           // floats per P row (64 taps + 1: consecutive voxels on consecutive banks)
+constexpr int FM_PPITCH = 33;           // floats per P row (32 taps of one half + 1: consecutive voxels on consecutive banks)
 
 __device__ __forceinline__ int fm_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+typedef __attribute__((address_space(3))) void *fm_lptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned fm_u32x4;
+__device__ __forceinline__ void fm_dma16(fm_u32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
 
 __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                              const float *__restrict__ target, float *__restrict__ probs,
                                                              float *__restrict__ logits, float *__restrict__ partials,
-                                                             int din_log2, float gamma, float epsilon) {
+                                                             int din_log2, unsigned x_bytes, float gamma, float epsilon) {
+    // LDS: staged operands (36 KiB), later overwritten by ONE 32-tap half of P at a time (28 KiB): 4 workgroups per CU.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *As = smem;                                   // [224][128 B] bf16 rows, slot-swizzled
+    char *As = smem;                                   // [224][128 B] bf16 rows, slot-swizzled (source side)
     char *Ws = smem + FM_ROWS * 128;                   // [64 taps][128 B]
-    float *P = reinterpret_cast<float *>(smem);        // [216][65] f32, written after the MFMAs (aliases As/Ws)
+    float *P = reinterpret_cast<float *>(smem);        // [216][33] f32
     __shared__ float red[4][4];
-    const int li = din_log2, n = 1 << li, nb = n >> 2;
-    const int blk = blockIdx.x, b = blockIdx.y;
+    const int li = din_log2, n = 1 << li, nb = n >> 2, nblk = nb * nb * nb;
+    // XCD-aware order (workgroups are dealt round-robin over 8 XCDs): block g takes item (g % 8) * (T / 8) + g / 8 of the
+    // sample-major list, so the 6^3 halo tiles of neighbouring blocks of one sample are re-read from ONE XCD's L2.
+    const int T = gridDim.x;
+    const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
+    const int blk = wi % nblk, b = wi / nblk;
     const int bw = blk % nb, bh = (blk / nb) % nb, bd = blk / (nb * nb);
     const int m0d = bd * 4, m0h = bh * 4, m0w = bw * 4;
-    const char *xb = reinterpret_cast<const char *>(x + ((size_t)b << (3 * li)) * FB_CIN);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // stage: 224 rows x 8 slots of 16 B
-#pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        const int idx = tid + 256 * it, row = idx >> 3, slot = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < 216) {
+    // stage A by LDS-DMA: 224 rows x 8 slots = 28 wave instructions (8 rows each); rows >= 216 and halo voxels outside
+    // the grid come back as zeros (out-of-range buffer offsets)
+    {
+        fm_u32x4 rs;
+        const unsigned long long base = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
+        rs[2] = __builtin_amdgcn_readfirstlane(x_bytes);
+        rs[3] = 0x00020000u;
+        const unsigned lds0 = (unsigned)(unsigned long long)(fm_lptr_t)As;
+        const int pos = lane & 7, rsub = lane >> 3;
+        for (int it = wv; it < FM_ROWS / 8; it += 4) {
+            const int row = it * 8 + rsub;
             const int zw = row % 6, zh = (row / 6) % 6, zd = row / 36;
             const int id = m0d - 1 + zd, ih = m0h - 1 + zh, iw = m0w - 1 + zw;
-            if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
-                v = *reinterpret_cast<const uint4 *>(xb + (((((size_t)id << li) + ih) << li) + iw) * (FB_CIN * 2) + slot * 16);
+            const bool ok = row < 216 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+            const int g = pos ^ ((row >> 1) & 7);
+            const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
+            fm_dma16(rs, vo, lds0 + it * 1024);
         }
-        *reinterpret_cast<uint4 *>(As + fm_lds_off(row, slot)) = v;
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -157,9 +175,10 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
         for (int e = 0; e < 4; ++e) { o[e] = static_cast<__bf16>(w0[e]); o[4 + e] = static_cast<__bf16>(w1[e]); }
         *reinterpret_cast<bf16x8 *>(Ws + fm_lds_off(row, slot)) = o;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // MFMA: wave -> tap tile nt = wv & 1, row tiles mt = (wv >> 1) + 2 j
+    // MFMA: wave -> tap half nt = wv & 1, row tiles mt = (wv >> 1) + 2 j
     const int fr = lane & 31, fh = lane >> 5;
     const int nt = wv & 1, mt0 = wv >> 1;
     uint4 fb[4];
@@ -180,30 +199,34 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
             }
         }
     }
-    __syncthreads();   // every wave is done reading As/Ws: P may overwrite them
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int mt = mt0 + 2 * j;
-        if (mt < 7) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
-                if (row < 216) P[row * FM_PPITCH + nt * 32 + fr] = acc[j][q];
-            }
-        }
-    }
-    __syncthreads();
 
-    // gather: wave -> output parity (pd, ph); lane -> cell; both pw parities per lane
+    // wave -> output parity (pd, ph); lane -> cell; both pw parities per lane.  Tap half h holds td = 2h, 2h+1, i.e. the
+    // terms with ad = h of every output: two passes of {waves of that half publish P, everyone gathers its 4 terms}.
     const int pd = wv >> 1, ph = wv & 1;
     const int mw = lane & 3, mh = (lane >> 2) & 3, md = lane >> 4;
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-    for (int ad = 0; ad < 2; ++ad) {
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();   // operands (h = 0) / previous half (h = 1) no longer read by anyone
+        if (nt == h) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int mt = mt0 + 2 * j;
+                if (mt < 7) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                        if (row < 216) P[row * FM_PPITCH + fr] = acc[j][q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int ad = h, td = 1 - pd + 2 * ad - 2 * h;          // tap row inside this half (0 or 1)
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah) {
             const int zd = md + pd - ad + 1, zh = mh + ph - ah + 1;
-            const int td = 1 - pd + 2 * ad, th = 1 - ph + 2 * ah;
+            const int th = 1 - ph + 2 * ah;
             const float *r = P + ((zd * 6 + zh) * 6 + mw) * FM_PPITCH + (td * 4 + th) * 4;
             acc0 += r[FM_PPITCH + 1] + r[3];                    // pw = 0: i = mw (tw 1), mw-1 (tw 3)
             acc1 += r[2 * FM_PPITCH + 0] + r[FM_PPITCH + 2];    // pw = 1: i = mw+1 (tw 0), mw (tw 2)
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
     bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
     if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
     __syncthreads();
-    if (tid < 4) partials[((size_t)b * gridDim.x + blk) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 4) partials[((size_t)b * nblk + blk) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nblk) {
@@ -265,8 +288,9 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *partials = reinterpret_cast<float *>(workspace);
     if (dtype == VV_BF16)
-        VV_LAUNCH(final_bce_mfma_kernel, dim3(nblk, batch), dim3(256), (size_t)216 * FM_PPITCH * 4, st,
-                  reinterpret_cast<const __bf16 *>(x), w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
+        VV_LAUNCH(final_bce_mfma_kernel, dim3(nblk * batch), dim3(256), (size_t)FM_ROWS * 128 + 64 * 128, st,
+                  reinterpret_cast<const __bf16 *>(x), w_keras, target, probs, logits, partials, vv_log2(side),
+                  (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
     else
         VV_LAUNCH((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
