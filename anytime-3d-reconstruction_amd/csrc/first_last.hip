@@ -255,6 +255,116 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
     if (tid < 4) partials[((size_t)b * nblk + blk) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+__device__ float vv_zero_word = 0.f;
+
+// first_conv (bf16): Conv3D k4 s2 SAME with ONE input channel -- a [rows x 64 taps] x [64 x 64] product per 128-row
+// tile with the taps gathered from the float32 occupancy grid.  The layer is latency-bound (one K chunk per tile: gather
+// -> LDS -> 8 MFMAs -> store, PMC: 68 % of wave time parked on vmcnt), so each workgroup walks several tiles and issues
+// the NEXT tile's 32 gathers per thread before it multiplies and stores the current one.
+__global__ __launch_bounds__(256) void first_conv_bf16_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              __bf16 *__restrict__ y, int batch, int din_log2, int act) {
+    constexpr int COUT = 64, EPITCH = COUT * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char Bs[64 * 128];         // [co][64 taps] bf16, slot-swizzled
+    __shared__ __attribute__((aligned(16))) char As[128 * 128];        // [row][64 taps] bf16, slot-swizzled
+    __shared__ __attribute__((aligned(16))) char Es[128 * EPITCH];     // output tile [row][64 co] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = din_log2, lo = li - 1, n = 1 << li, omsk = (1 << lo) - 1;
+    const long M = (long)batch << (3 * lo);
+    const int ntiles = (int)((M + 127) >> 7);
+    const int pos = tid & 7, r0 = tid >> 3;
+    const int gchunk = pos ^ ((r0 >> 1) & 7);
+
+    for (int i = tid; i < 64 * 8; i += 256) {            // weights: 64 rows x 8 slots, once per workgroup
+        const int row = i >> 3, slot = i & 7;
+        *reinterpret_cast<uint4 *>(Bs + fm_lds_off(row, slot)) = *reinterpret_cast<const uint4 *>(wp + row * 64 + slot * 8);
+    }
+
+    // The gather only ISSUES loads (invalid taps read a zero word through a selected address, so nothing consumes the
+    // values here); conversion to bf16 happens when the tile is written to LDS, one loop iteration later.
+    float raw[4][8];
+    auto gather = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = (long)tile * 128 + r0 + 32 * i;
+            const int ow = (int)(m & omsk), oh = (int)((m >> lo) & omsk), od = (int)((m >> (2 * lo)) & omsk);
+            const long b = m >> (3 * lo);
+            const int d0 = 2 * od - 1, h0 = 2 * oh - 1, w0 = 2 * ow - 1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {                 // slot = taps (td, th0 + r, tw 0..3): one run of 4 voxels along w
+                const int td = gchunk >> 1, th = ((gchunk & 1) << 1) + r;
+                const bool ok = m < M && (unsigned)(d0 + td) < (unsigned)n && (unsigned)(h0 + th) < (unsigned)n;
+                const float *xr = x + ((((((b << li) + d0 + td) << li) + h0 + th) << li) + w0);
+                const float *p0 = (ok && w0 >= 0) ? xr : &vv_zero_word, *p1 = ok ? xr + 1 : &vv_zero_word;
+                const float *p2 = ok ? xr + 2 : &vv_zero_word, *p3 = (ok && w0 + 3 < n) ? xr + 3 : &vv_zero_word;
+                raw[i][4 * r + 0] = *p0; raw[i][4 * r + 1] = *p1; raw[i][4 * r + 2] = *p2; raw[i][4 * r + 3] = *p3;
+            }
+        }
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    int tile = blockIdx.x;
+    if (tile < ntiles) gather(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = static_cast<__bf16>(raw[i][e]);
+            *reinterpret_cast<bf16x8 *>(As + (r0 + 32 * i) * 128 + pos * 16) = v;
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) gather(tile + gridDim.x);    // in flight during the MFMAs and the stores below
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 fb = *reinterpret_cast<const uint4 *>(Bs + fm_lds_off(wn * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint4 fa = *reinterpret_cast<const uint4 *>(As + fm_lds_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb),
+                                                                 *reinterpret_cast<const bf16x8 *>(&fa), acc[i], 0, 0, 0);   // D[co][row]
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = wn * 32 + 8 * g + 4 * fh;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c);
+            if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][4 * g + e] * sc[e] + sh[e];
+                    if (act == VV_ACT_ELU) t = t > 0.f ? t : __expf(t) - 1.f;
+                    else if (act == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (act == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                    o[e] = static_cast<__bf16>(t);
+                }
+                *reinterpret_cast<bf16x4 *>(Es + (wm * 64 + i * 32 + fr) * EPITCH + c * 2) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, rl = idx >> 3, c = idx & 7;
+            const long m = (long)tile * 128 + rl;
+            if (m < M) *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + m * (COUT * 2) + c * 16) =
+                           *reinterpret_cast<const uint4 *>(Es + rl * EPITCH + c * 16);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nblk) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -295,5 +405,17 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
         VV_LAUNCH((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
     VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
+    return vv_launch_status();
+}
+
+// bf16 fast path of vv_conv3d_first_fwd (igemm.hip dispatches here): w_packed = vv_pack_conv_k4(cin = 1) = [64][64] bf16.
+int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,
+                              int side, int act, void *stream) {
+    const int li = vv_log2(side);
+    const long M = (long)batch << (3 * (li - 1));
+    const int ntiles = (int)((M + 127) / 128);
+    const int grid = ntiles < 2048 ? ntiles : 2048;
+    VV_LAUNCH(first_conv_bf16_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+              reinterpret_cast<const __bf16 *>(w_packed), scale, shift, reinterpret_cast<__bf16 *>(y), batch, li, act);
     return vv_launch_status();
 }

@@ -22,6 +22,9 @@
 
 #include "common.h"
 
+int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,
+                              int side, int act, void *stream);   // first_last.hip
+
 namespace {
 
 enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_CONVT = 2, MODE_FIRST = 3 };
@@ -332,14 +335,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 T vals[EPS];
+                // EPS/4 runs of 4 consecutive taps (tw = 0..3): one (td, th) row check and base address per run; only the
+                // two outer voxels of a run can fall off the grid along w (iw = 2 ow - 1 .. 2 ow + 2)
 #pragma unroll
-                for (int e = 0; e < EPS; ++e) {
-                    const int t = kc * BK + gchunk * EPS + e;
-                    const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
-                    const bool ok = rows[i].ok && (unsigned)(rows[i].d0 + td) < (unsigned)n &&
-                                    (unsigned)(rows[i].h0 + th) < (unsigned)n && (unsigned)(rows[i].w0 + tw) < (unsigned)n;
-                    const float v = ok ? xf[rows[i].off0 + ((((td << a.din_log2) + th) << a.din_log2) + tw)] : 0.f;
-                    vals[e] = static_cast<T>(v);
+                for (int r = 0; r < EPS / 4; ++r) {
+                    const int t0 = kc * BK + gchunk * EPS + 4 * r;
+                    const int td = t0 >> 4, th = (t0 >> 2) & 3;
+                    const bool rowok = rows[i].ok && (unsigned)(rows[i].d0 + td) < (unsigned)n && (unsigned)(rows[i].h0 + th) < (unsigned)n;
+                    const float *xr = xf + rows[i].off0 + (((td << a.din_log2) + th) << a.din_log2);
+                    const float v0 = (rowok && rows[i].w0 >= 0) ? xr[0] : 0.f;
+                    const float v1 = rowok ? xr[1] : 0.f, v2 = rowok ? xr[2] : 0.f;
+                    const float v3 = (rowok && rows[i].w0 + 3 < n) ? xr[3] : 0.f;
+                    vals[4 * r + 0] = static_cast<T>(v0); vals[4 * r + 1] = static_cast<T>(v1);
+                    vals[4 * r + 2] = static_cast<T>(v2); vals[4 * r + 3] = static_cast<T>(v3);
                 }
                 ra[i] = *reinterpret_cast<const uint4 *>(vals);
             }
@@ -645,6 +653,8 @@ VV_EXPORT int vv_conv3d_first_fwd(const float *x, const void *w_packed, const fl
     if (batch <= 0 || side < 2 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
     if ((long)batch * side * side * side >= (1L << 31)) return VV_ERR_SHAPE;
     const int o = side / 2;
+    if (dtype == VV_BF16 && cout == 64 && x && w_packed && y && vv_aligned16(y) && vv_aligned16(w_packed) && !getenv("VV_NO_FIRSTCONV"))
+        return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream);
     return run_igemm(MODE_FIRST, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64, side, 1, act, dtype, dtype, nullptr,
                      0, stream, batch);
 }
