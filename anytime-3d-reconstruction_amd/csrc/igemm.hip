@@ -205,15 +205,15 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
     return r;
 }
 
-template <typename T, int MODE, int BM, int BN>
+template <typename T, int MODE, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int BK = Elt<T>::BK;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 tiles per wave (waves laid out 2 x 2)
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
     constexpr bool DMA = MODE != MODE_FIRST;   // global -> LDS directly (global_load_lds_dwordx4), no VGPR round trip
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *As = smem;                       // [2][BM][128]
-    char *Bs = smem + 2 * BM * ROWB;       // [2][BN][128]
+    char *As = smem;                            // [STAGES][BM][128]
+    char *Bs = smem + STAGES * BM * ROWB;       // [STAGES][BN][128]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     (void)wbase_reg;
 
     // Tile-uniform list of taps that touch real data for at least one row (smem tail, lives through the K loop).
-    int *taplist = reinterpret_cast<int *>(smem + 2 * (BM + BN) * ROWB);   // [64] + 2 mask words
+    int *taplist = reinterpret_cast<int *>(smem + STAGES * (BM + BN) * ROWB);   // [64] + 2 mask words
     int nvalid = kc_end - kc_begin, vb = kc_begin;                         // dense / first: chunks are the list
     if constexpr (TAPS) {
         unsigned *mw = reinterpret_cast<unsigned *>(taplist + 64);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const unsigned vo = kin ? woff[i] : OOB;
-            dma16(rsW, vo, (unsigned)(kc * ROWB), lds0 + 2 * BM * ROWB + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB);
+            dma16(rsW, vo, (unsigned)(kc * ROWB), lds0 + STAGES * BM * ROWB + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB);
         }
     };
 
@@ -377,38 +377,67 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int fr = lane & 31, fh = lane >> 5;
     int vi = vb;
     const int ve = vb + nvalid;
-    if (vi < ve) {
-        if constexpr (DMA) issue(vi, 0);
-        else { gload(vi); lstore(0); }
-    }
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int buf = 0;
-    for (; vi < ve; ++vi) {
-        const bool more = vi + 1 < ve;
-        if (more) {
-            if constexpr (DMA) issue(vi + 1, buf ^ 1);
-            else gload(vi + 1);
-        }
+    auto compute = [&](int buf) {
         const char *Ac = As + buf * BM * ROWB, *Bc = Bs + buf * BN * ROWB;
+        // fragments of k-step ks+1 are read while the MFMAs of k-step ks issue (ping-pong registers): a wave does not
+        // sit on its own LDS latency between k-steps
+        uint4 fa[2][TM], fb[2][TN];
+        auto read_frags = [&](int ks, uint4 *pa, uint4 *pb) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) pa[i] = *reinterpret_cast<const uint4 *>(Ac + lds_off(wm * (BM / 2) + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pb[j] = *reinterpret_cast<const uint4 *>(Bc + lds_off(wn * (BN / 2) + j * 32 + fr, ks * 2 + fh));
+        };
+        read_frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            uint4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const uint4 *>(Ac + lds_off(wm * (BM / 2) + i * 32 + fr, ks * 2 + fh));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const uint4 *>(Bc + lds_off(wn * (BN / 2) + j * 32 + fr, ks * 2 + fh));
+            if (ks + 1 < 4) read_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mma_step<T>(fb[j], fa[i], acc[i][j]);   // D[n][m]: lane = row m, registers walk n
+                for (int j = 0; j < TN; ++j) mma_step<T>(fb[ks & 1][j], fa[ks & 1][i], acc[i][j]);   // D[n][m]: lane = row m, registers walk n
         }
-        if (more) lstore(buf ^ 1);
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk vi+1 has landed (it flew during the MFMAs)
+    };
+    if constexpr (DMA && STAGES > 2) {
+        // STAGES-deep LDS ring, ONE barrier per chunk: chunk i+STAGES-1 is issued into the stage chunk i-1 just left, and
+        // the wait before the barrier is a COUNTED vmcnt that leaves the STAGES-2 younger chunks in flight.
+        constexpr int LPC = RA + RB;              // LDS-DMA instructions per thread per chunk
+        const int nv = ve - vb;
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nv) issue(vb + s, s);
+        int st = 0;
+        for (int i = 0; i < nv; ++i) {
+            const int younger = min(STAGES - 2, nv - 1 - i);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPC) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (i + STAGES - 1 < nv) issue(vb + i + STAGES - 1, st == 0 ? STAGES - 1 : st - 1);
+            compute(st);
+            st = st + 1 == STAGES ? 0 : st + 1;
+        }
         __syncthreads();
-        buf ^= 1;
+    } else {
+        if (vi < ve) {
+            if constexpr (DMA) issue(vi, 0);
+            else { gload(vi); lstore(0); }
+        }
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (; vi < ve; ++vi) {
+            const bool more = vi + 1 < ve;
+            if (more) {
+                if constexpr (DMA) issue(vi + 1, buf ^ 1);
+                else gload(vi + 1);
+            }
+            compute(buf);
+            if (more) lstore(buf ^ 1);
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk vi+1 has landed (it flew during the MFMAs)
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // ---- epilogue.  The MFMAs were issued weights-first, so a lane owns ONE output row m = lane & 31 and its 16
@@ -537,21 +566,37 @@ bool use_pos_major(int mode, int din, int batch) {
     return false;
 }
 
+template <typename T, int MODE, int BN, int STAGES>
+void launch_k(const IgemmArgs &a, dim3 grid, hipStream_t st) {
+    size_t lds = (size_t)STAGES * (128 + BN) * ROWB + 272;   // stages + tap list
+    const size_t lds_epi = (size_t)128 * (BN * 4 + 16);
+    if (lds_epi > lds) lds = lds_epi;
+    static const bool attr_set = [] {
+        size_t m = (size_t)STAGES * (128 + BN) * ROWB + 272;
+        if ((size_t)128 * (BN * 4 + 16) > m) m = (size_t)128 * (BN * 4 + 16);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, BN, STAGES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)m);
+        return true;
+    }();
+    (void)attr_set;
+    VV_LAUNCH((igemm_kernel<T, MODE, 128, BN, STAGES>), grid, dim3(256), lds, st, a);
+}
+
 template <typename T, int MODE>
 int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     const int tiles = ((a.M + p.bm - 1) / p.bm) * ((a.N + p.bn - 1) / p.bn);
     dim3 grid(tiles * p.split * p.nparity);
-    size_t lds = (size_t)2 * (p.bm + p.bn) * ROWB + 272;   // stages + tap list
-    const size_t lds_epi = (size_t)p.bm * (p.bn * 4 + 16);
-    if (lds_epi > lds) lds = lds_epi;
-    static const bool attr_set = [] {  // 64 KiB of dynamic LDS for the 128x128 tile
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (128 * 4 + 16));   // >= 2*(128+128)*128 + 272
-        return true;
-    }();
-    (void)attr_set;
-    if (p.bn == 128) VV_LAUNCH((igemm_kernel<T, MODE, 128, 128>), grid, dim3(256), lds, st, a);
-    else VV_LAUNCH((igemm_kernel<T, MODE, 128, 64>), grid, dim3(256), lds, st, a);
+    static const int stages_env = getenv("VV_STAGES") ? atoi(getenv("VV_STAGES")) : 2;
+    const int stages = (MODE == MODE_FIRST || sizeof(T) == 4) ? 2 : stages_env;   // deep ring: bf16 LDS-DMA modes only
+    if (p.bn == 128) {
+        if (stages == 3) launch_k<T, MODE, 128, 3>(a, grid, st);
+        else if (stages == 4) launch_k<T, MODE, 128, 4>(a, grid, st);
+        else launch_k<T, MODE, 128, 2>(a, grid, st);
+    } else {
+        if (stages == 3) launch_k<T, MODE, 64, 3>(a, grid, st);
+        else if (stages == 4) launch_k<T, MODE, 64, 4>(a, grid, st);
+        else launch_k<T, MODE, 64, 2>(a, grid, st);
+    }
     if (p.split > 1) {
         const size_t total = (size_t)p.nparity * a.M * (a.N / 4);
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
