@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--latent', type=int, default=64)
     ap.add_argument('--cpu-samples', type=int, default=256, help='samples per CPU-baseline pass (0 = skip)')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
+                    help="'eval' = the BASELINE.json headline (default); 'train' = fit() steps (f32, gradients all-reduced over RCCL for N>1)")
     return ap.parse_args()
 
 
@@ -58,6 +60,38 @@ def cpu_baseline(cfg, ep, dp, x, eps, n, min_seconds=10.0, max_passes=50):
     return r, {'value': n * passes / dt, 'unit': 'reconstructions/s', 'cores': co.num_threads(), 'kind': 'port',
                'sample': '%d pass(es) over %d of the %d synthetic 32^3 samples, fp32 C oracle (oracle/voxvae_oracle.c, OpenMP), %.1f s'
                          % (passes, n, x.shape[0], dt)}
+
+
+def bench_train(a, model, x, eps, world, rank, dev, dist):
+    """Training-step throughput (BASELINE.json configs[3]: batch sharded over the ranks, gradients summed by RCCL)."""
+    from voxvae import train as T
+    tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-4, world_size=world)
+    for _ in range(a.warmup):
+        tr.step(x, x, eps)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        kl, stats, metrics = tr.step(x, x, eps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank == 0:
+        print(json.dumps({'metric': '32^3 voxel VAE training samples/sec (fit: fwd + bwd + Adam)', 'value': world * a.batch * a.steps / el,
+                          'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el / a.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+                          'config': {'workload': 'ModelNet40 VAE fit(), %d^3 voxels, latent %d, batch %d per GPU (BASELINE.json configs[3])'
+                                                 % (a.voxel, a.latent, a.batch), 'global_batch': a.batch * world,
+                                     'parallelism': 'dp%d, bucketed RCCL all-reduce of gradients, per-rank BatchNorm' % world},
+                          'final_loss_shape': float(metrics[0]), 'final_loss_kl': float(kl.mean())}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -80,6 +114,8 @@ def main():
     from voxvae import engine as E
     from voxvae import synthetic as syn
     from voxvae import workload
+    if a.mode == 'train':
+        a.dtype = 'f32'            # training runs on the exact-f32 MFMA path this round
     voxvae.set_default_dtype(a.dtype)
     voxvae.set_default_device(dev)
     import src.module.nolbo as nolbo
@@ -96,6 +132,9 @@ def main():
 
     def step():
         return model.eval_forward_device(x, x, eps)
+
+    if a.mode == 'train':
+        return bench_train(a, model, x, eps, world, rank, dev, dist)
 
     # ---- per-layer breakdown (outside the timed region) -> dominant kernel
     lm = {n: v for n, v, _ in workload.layer_macs(cfg)}

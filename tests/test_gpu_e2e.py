@@ -99,3 +99,55 @@ def test_f32_batch_invariance_and_c_oracle():
     c = co.vae_eval_forward(cfg, ep, dp, x[12:], x[12:], eps[12:])
     assert np.abs(big['logits'][12:] - c['logits']).max() < 1e-3
     np.testing.assert_allclose(big['stats'][12:, 0], c['bce'], rtol=1e-4)
+
+
+@pytest.mark.parametrize('dtname,B', [('f32', 8), ('bf16', 8)])
+def test_d64_vae_config_against_c_oracle(dtname, B):
+    """BASELINE configs 3/5 shape (the reference's native 64^3 grid, test_modelnet_VAE.py:174-189): D=64, L=64."""
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(64, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x = syn.make_voxels(B, 64, seed=64)
+    eps = syn.make_eps(B, 64, seed=65)
+    r = _run(cfg, ep, dp, x, x, eps, dtname)
+    c = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
+    s = r['stats'].astype(np.float64)
+    iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3]).mean()
+    iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64)).mean()
+    err = np.abs(r['logits'] - c['logits']).max()
+    print('\n[d64 %s] IoU gpu %.6f cpu %.6f ; max|dlogit| %.3e (max|logit| %.1f)' % (dtname, iou_g, iou_c, err, np.abs(c['logits']).max()))
+    assert abs(iou_g - iou_c) <= 1e-3
+    if dtname == 'f32':
+        assert err < 1e-3
+        safe = np.abs(c['logits']) > 1e-4
+        assert np.array_equal((r['logits'] >= 0)[safe], (c['logits'] >= 0)[safe])
+
+
+def test_full_batch_256_properties_bf16():
+    """BASELINE.json's headline size (B=256, 32^3, bf16): size-independent properties instead of a full oracle run --
+    (1) any sample computed inside the 256-batch equals the same sample computed in a batch of 5 (tiles, split-K and
+    position-major row order all change with B); (2) permuting the batch permutes the outputs; (3) IoU against the C
+    oracle on a 16-sample subset within 1e-3."""
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(32, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x = syn.make_voxels(256, 32, seed=256)
+    eps = syn.make_eps(256, 64, seed=257)
+    big = _run(cfg, ep, dp, x, x, eps, 'bf16')
+    pick = [0, 37, 128, 200, 255]
+    small = _run(cfg, ep, dp, x[pick], x[pick], eps[pick], 'bf16')
+    d = np.abs(big['logits'][pick] - small['logits']).max()
+    assert d < 0.02 * np.abs(big['logits']).max(), d            # bf16 path, different accumulation splits
+    assert np.abs(big['stats'][pick, 1:] - small['stats'][:, 1:]).max() <= 0.002 * 32768
+    perm = np.random.default_rng(0).permutation(256)
+    pb = _run(cfg, ep, dp, x[perm], x[perm], eps[perm], 'bf16')
+    np.testing.assert_array_equal(pb['stats'], big['stats'][perm])          # same tiles, same order of operations per sample
+    sub = list(range(0, 256, 16))
+    c = co.vae_eval_forward(cfg, ep, dp, x[sub], x[sub], eps[sub])
+    s = big['stats'][sub].astype(np.float64)
+    iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3]).mean()
+    iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64)).mean()
+    print('\n[B256 bf16] IoU gpu %.6f cpu %.6f' % (iou_g, iou_c))
+    assert abs(iou_g - iou_c) <= 1e-3
