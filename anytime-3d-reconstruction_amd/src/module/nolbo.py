@@ -33,6 +33,10 @@ def _st():
 class _ModelnetBase(object):
     _variational = True
 
+    @property
+    def _latent_dim(self):
+        return self._enc_backbone_str['z_category_dim']
+
     def _buildModel(self):
         print('build Models...')
         self._encoder = ae3D.encoder3D(structure=self._enc_str)
@@ -55,7 +59,7 @@ class _ModelnetBase(object):
         enc_out = self._enc_eng.forward(x)
         if not self._variational:
             return enc_out, self._to_act(enc_out), None
-        Lz = self._enc_backbone_str['z_category_dim']
+        Lz = self._latent_dim
         if enc_out.shape[1] != 2 * Lz:
             raise ValueError('VAE encoder must emit 2*z_category_dim channels, got %d' % enc_out.shape[1])
         eps = torch.randn(x.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
@@ -89,7 +93,7 @@ class _ModelnetBase(object):
         mask, scale = None, 1.0
         if self._dropout:      # reference nolbo.py:1423-1425: rate ~ U[0,1) per step, inverted dropout on z
             rate = float(np.random.rand()) if drop_rate is None else float(drop_rate)
-            Lz = self._enc_backbone_str['z_category_dim']
+            Lz = self._latent_dim
             if drop_mask is None:
                 drop_mask = (np.random.rand(x.shape[0], Lz) >= rate).astype('float32')
             mask, scale = self._dev(drop_mask), 1.0 / (1.0 - rate)
@@ -110,7 +114,7 @@ class _ModelnetBase(object):
         input_images, output_images, category_list = inputs
         x, y, onehot = self._dev(input_images), self._dev(output_images), self._dev(category_list)
         cats = self._dev(category_vectors)
-        B, Lz, C = x.shape[0], self._enc_backbone_str['z_category_dim'], cats.shape[0]
+        B, Lz, C = x.shape[0], self._latent_dim, cats.shape[0]
         z, z_act, _ = self._encode_latent(x, _eps)
         mask = None
         if missing_prob > 0:
@@ -238,3 +242,74 @@ class nolboSingleObject_modelnet_category_VAE(_ModelnetBase):
         """reference nolbo.py:1411-1447 -> (loss_kl, loss_shape, pr, rc)."""
         kl, m = self._fit(inputs, _eps, _mask, _rate)
         return DeviceArray(kl.mean()), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
+
+
+class nolboSingleObject_VAE(_ModelnetBase):
+    """Voxel half of the reference's image -> 3D model, nolbo.py:750-982 (BASELINE.json configs[2], test_pascal_VAE_dr.py):
+    decoder3D + losses + latent masking / prior correction + modality dropout run on the HIP path exactly as in the
+    modelnet classes (the reference's getEval bodies are line-for-line the same algorithm, nolbo.py:856-928 vs 1449-1528).
+
+    The 2D image encoder (Darknet19 backbone + head2D, reference src/net_core/darknet.py) is OUT OF SCOPE of the voxel
+    hot path: pass it as `encoder_backbone` -- any callable images -> head output [B, 2*z_dim]
+    (numpy / torch / DeviceArray).  With no backbone the `input_images` are taken to BE head outputs [B, 2*z_dim]
+    (synthetic head features).  fit() trains the decoder only through this class; the 2D encoder's
+    training stays with whatever framework provides it."""
+    _variational = True
+
+    def __init__(self, nolbo_structure,
+                 backbone_style=None, encoder_backbone=None,
+                 dropout=False,
+                 learning_rate=1e-4):
+        self._enc_backbone_str = nolbo_structure['encoder_backbone']
+        self._enc_head_str = nolbo_structure.get('encoder_head')
+        self._dec_str = nolbo_structure['decoder']
+        self._backbone_style = backbone_style
+        self._encoder_backbone = encoder_backbone
+        self._dropout = dropout
+        self._learning_rate = learning_rate
+        self._buildModel()
+
+    @property
+    def _latent_dim(self):
+        return self._enc_backbone_str['z_dim']
+
+    def _buildModel(self):
+        print('build Models...')
+        if self._encoder_backbone is None and self._backbone_style is not None:
+            self._encoder_backbone = self._backbone_style(name=self._enc_backbone_str['name'])
+        # ==============set decoder3D
+        self._decoder = ae3D.decoder3D(structure=self._dec_str)
+        self._dec_eng = self._decoder._engine
+        self._device = self._dec_eng.device
+        self._act_dt = self._dec_eng.dt
+        print('done')
+
+    def _encode_latent(self, x, eps=None, want_kl=False):
+        enc_out = x if self._encoder_backbone is None else self._encoder_backbone(x)
+        enc_out = self._dev(enc_out)
+        Lz = self._latent_dim
+        if enc_out.dim() != 2 or enc_out.shape[1] != 2 * Lz:
+            raise ValueError('the 2D encoder must emit [B, %d] (mean | logVar), got %s' % (2 * Lz, tuple(enc_out.shape)))
+        eps = torch.randn(enc_out.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
+        z, z_act, kl, _, _ = _E.reparam_kl(enc_out, eps, Lz, self._act_dt)
+        return z, z_act, kl
+
+    def _dev(self, a):
+        if callable(getattr(a, 'numpy', None)) and not isinstance(a, (torch.Tensor, DeviceArray)):
+            a = a.numpy()
+        return as_device_f32(a, self._device)
+
+    def fit(self, inputs):
+        raise NotImplementedError('nolboSingleObject_VAE.fit needs the 2D Darknet encoder (out of the voxel hot-path scope)')
+
+    def saveEncoder(self, save_path):
+        pass   # the 2D encoder is not owned by this class
+
+    def loadEncoder(self, load_path, file_name=None):
+        pass
+
+    def saveModel(self, save_path):
+        self.saveDecoder(save_path=save_path)
+
+    def loadModel(self, load_path):
+        self.loadDecoder(load_path=load_path)

@@ -168,3 +168,41 @@ def test_entry_scripts_run_on_synthetic_data(tmp_path):
     assert cv.shape == (40, 64) and os.path.exists(tmp_path / 'category_vectors.npy')
     l8 = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2)
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
+
+
+def test_pascal_vae_decoder_half_config3():
+    """BASELINE.json configs[2] (test_pascal_VAE_dr.py): latent 16, 64^3 decoder, 12 classes, missing_prob 0.9 -> two
+    decoder passes; the 2D image encoder is replaced by supplied head outputs [B, 32]."""
+    import voxvae
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('bf16')
+    import src.module.nolbo as nolbo
+    B, Lz, C, D = 16, 16, 12, 64
+    dec_cfg = syn.make_config(D, Lz, True)['decoder']
+    cfg = {'encoder_backbone': {'name': 'nolbo_backbone', 'z_dim': Lz},
+           'encoder_head': {'name': 'nolbo_head', 'output_dim': 2 * Lz, 'filter_num_list': [], 'filter_size_list': [], 'activation': 'elu'},
+           'decoder': dec_cfg}
+    m = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg)
+    dp = syn.make_decoder_params(dec_cfg)
+    m._decoder.set_weights_dict(dp)
+    rng = np.random.default_rng(3)
+    head = rng.standard_normal((B, 2 * Lz)).astype(np.float32)
+    y = syn.make_voxels(B, D, seed=9)
+    oh, cats = syn.make_onehot(B, C), syn.make_category_vectors(C, Lz)
+    eps, eps2, mask = syn.make_eps(B, Lz), syn.make_eps(B, Lz, seed=8), syn.make_mask(B, Lz, 0.9)
+    out = m.getEval(inputs=(head, y, oh), category_vectors=cats, missing_prob=0.9, _eps=eps, _mask=mask, _eps2=eps2)
+    assert len(out) == 10 and np.array(out[0]).shape == (B, D, D, D, 1) and np.array(out[5]).shape == (B, D, D, D, 1)
+    # oracle: same latent algebra in numpy, decoder + losses through the C restatement
+    mu, lv = no.split_mean_logvar(head.astype(np.float64), Lz)
+    z = no.sampling(mu, lv, eps) * mask
+    z = np.where(z == 0, cats.astype(np.float64).mean(0)[None, :] * np.ones_like(z), z)
+    idx, _ = no._nearest_category_acc(z, cats.astype(np.float64), oh, mask=mask.astype(np.float64))
+    zc = np.where(mask == 0, cats[idx].astype(np.float64) + eps2, z)
+    for zz, (loss_i, pr_i, rc_i) in ((z, (1, 2, 3)), (zc, (6, 7, 8))):
+        lg = co.decoder3D_logits(dec_cfg, dp, zz.astype(np.float32))
+        probs, bce, tp, fp, fn = co.sigmoid_bce_counts(lg, y)
+        pr, rc = no.pr_rc(tp.astype(np.float64), fp.astype(np.float64), fn.astype(np.float64))
+        assert abs(float(out[loss_i]) - bce.mean()) < 0.02 * bce.mean()
+        assert abs(float(out[pr_i]) - pr) < 5e-3 and abs(float(out[rc_i]) - rc) < 5e-3
+    np.testing.assert_allclose(np.array(m._z_category_corrected), zc, atol=2e-5)
