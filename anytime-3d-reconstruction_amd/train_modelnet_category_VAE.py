@@ -17,11 +17,11 @@ def train(
         dataset_path=None,
         save_path=None, load_path=None,
         load_decoder_path=None, load_decoder_name=None,
-        max_iter=None, model_class='VAE',
+        max_iter=None, model_class='VAE', dropout=False,
 ):
     import src.module.nolbo as nolbo
     cls = nolbo.nolboSingleObject_modelnet_category_VAE if model_class == 'VAE' else nolbo.nolboSingleObject_modelnet_category_AE
-    model = cls(nolbo_structure=config, learning_rate=learning_rate)
+    model = cls(nolbo_structure=config, learning_rate=learning_rate, dropout=dropout)   # dropout=True: the _dr scripts
     voxel = config['encoder']['input_shape'][0]
     data_loader_train = dataLoader(data_path=dataset_path, trainortest='train', voxel=voxel)
     data_loader_test = dataLoader(data_path=dataset_path, trainortest='test', voxel=voxel)

@@ -1,0 +1,17 @@
+"""Entry point mirroring the reference's train_modelnet_category_VAE_dr.py: the VAE training script with
+`dropout=True` (latent dropout with a per-step random rate, reference nolbo.py:1423-1425) -- a 1-line diff there too."""
+import sys
+
+import _entry_common as C
+import voxvae
+from train_modelnet_category_VAE import train
+
+latent_dim = 64
+config = C.make_config(latent_dim, 64, True)
+
+if __name__ == '__main__':
+    a = C.parse(__doc__, train=True)
+    voxvae.set_default_dtype('f32')
+    train(training_epoch=a.epochs, learning_rate=a.lr, batch_size=a.batch, config=C.make_config(a.latent, a.voxel, True),
+          dataset_path=a.dataset_path, save_path=a.save_path, load_path=a.load_path, max_iter=a.max_iter, dropout=True)
+    sys.exit(0)

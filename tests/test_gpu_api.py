@@ -168,6 +168,13 @@ def test_entry_scripts_run_on_synthetic_data(tmp_path):
     assert cv.shape == (40, 64) and os.path.exists(tmp_path / 'category_vectors.npy')
     l8 = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2)
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
+    # latent-dropout training (the _dr scripts) and the (D*D, D) text dumps of test_modelnet_3D.py
+    res = tr.train(training_epoch=1, learning_rate=1e-3, batch_size=4, config=cfg, dataset_path='synthetic:16:16', max_iter=2, dropout=True)
+    assert np.all(np.isfinite(res[0]))
+    import test_modelnet_3D as t3
+    t3.test(dataset_path='synthetic:8:16', batch_size=2, save_dir=str(tmp_path / 'dump'), voxel=16, missing_prs=(0.5,))
+    m = np.loadtxt(tmp_path / 'dump' / '001_0.5_VAE.txt')
+    assert m.shape == (256, 16) and m.min() >= 0 and m.max() <= 1
 
 
 def test_pascal_vae_decoder_half_config3():
