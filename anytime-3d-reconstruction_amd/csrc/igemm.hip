@@ -10,12 +10,15 @@
 // MODE_FIRST: Conv3D k4 s2 SAME with Cin = 1 on the float32 occupancy grid: K = the 64 taps of the 4x4x4 window,
 //              gathered element-wise from x (two 4-voxel runs per 16-byte slot) and converted on the fly
 //
-// Channels-last makes every K chunk of one row a contiguous 128-byte segment (or zeros, for a tap in the
-// SAME padding), so both operands are staged as [rows][128 B] LDS images, XOR-swizzled per 16-byte slot so the
+// Channels-last makes every K chunk of one row a contiguous 128-byte segment (or zeros, for a tap in the SAME
+// padding), so both operands are staged as [rows][128 B] LDS images by LDS-DMA (buffer_load_dwordx4 ... lds issued from
+// inline asm; out-of-range descriptors offsets deposit zeros), XOR-swizzled per 16-byte slot on the SOURCE side so the
 // ds_read_b128 fragment reads are bank-conflict free, and consumed by v_mfma_f32_32x32x16_bf16 (bf16) or
-// v_mfma_f32_32x32x2_f32 (exact-f32 parity mode).  One 256-thread workgroup (4 waves, 2x2) owns a BM x BN tile;
-// global loads of chunk k+1 are in flight while chunk k is multiplied (register prefetch + LDS double buffer).
-// Split-K writes f32 slabs that igemm_splitk_epilogue sums in a fixed order (deterministic).
+// v_mfma_f32_32x32x2_f32 (exact-f32 parity mode).  One 256-thread workgroup (4 waves, 2x2) owns a 128 x BN tile; the
+// DMA of chunk k+1 flies while chunk k is multiplied (2-stage LDS ring; a deeper ring with counted vmcnt is available
+// through the STAGES parameter but measured slower than 2 stages x 2 workgroups per CU).  Small grids run position-major
+// with per-tile tap lists (padded taps skipped); work is ordered XCD-aware.  Split-K writes f32 slabs that
+// igemm_splitk_epilogue sums in a fixed order (deterministic).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -239,8 +242,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // position c ^ f(row).  f is the same for rows r0 + 32 i.
     const int pos = tid & 7, r0 = tid >> 3;
     const int gchunk = pos ^ ((r0 >> 1) & 7);
-    const char *Ab = reinterpret_cast<const char *>(a.A);
-    const char *Wb = reinterpret_cast<const char *>(a.W) + (size_t)parity * a.N * a.K * sizeof(T);
 
     RowCtx rows[RA];
 #pragma unroll
@@ -266,8 +267,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < RB; ++i)
         woff[i] = (n0 + r0 + 32 * i < a.N) ? (unsigned)(((size_t)parity * a.N + n0 + r0 + 32 * i) * a.K * sizeof(T)) + gchunk * 16 : OOB;
-    const char *wbase_reg[1] = {Wb};  // (register path below indexes weights through woff as well)
-    (void)wbase_reg;
 
     // Tile-uniform list of taps that touch real data for at least one row (smem tail, lives through the K loop).
     int *taplist = reinterpret_cast<int *>(smem + STAGES * (BM + BN) * ROWB);   // [64] + 2 mask words
