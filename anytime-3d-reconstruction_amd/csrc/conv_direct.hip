@@ -1,0 +1,266 @@
+// Direct strided convolution on MFMA with the input phase tile resident in LDS (bf16, gfx950).
+//
+// Conv3D k4 s2 SAME (autoencoder3D.py:26-39): out[o] = sum_t x[2o - 1 + t] W[t].  Writing t = 2a + q per axis
+// (a, q in {0,1}) gives x index 2(o + a) + q - 1: for a fixed input phase q = (qd,qh,qw) the layer is a k2 s1
+// convolution over the phase sub-grid X_q[j] = x[2j + q - 1], j = o + a.  A 4 x 8 x 8 box of outputs therefore needs,
+// per phase, only the 5 x 9 x 9 sub-grid tile, and its 8 taps a read shifted windows of that one tile.  The implicit
+// GEMM re-fetches every input row from L2 once per tap (64 x 128 B per output row, 2.2x its input from HBM/MALL by
+// FETCH_SIZE); here each workgroup stages 8 phase tiles of 405 rows instead of 64 im2col tiles of 256 rows.
+//
+//   workgroup  : 512 threads = 8 waves, 256 outputs x 128 channels; wave (wm, wn) owns output plane od0 + wm
+//                (64 outputs = 2 row tiles) x 64 channels (2 channel tiles); one workgroup per CU, 2 waves per SIMD
+//   LDS        : phase tile [405(+3)][128 B], slot XOR jw & 7 (conflict-free for every tap and both ds_read_b128 lane
+//                groups at row pitch 9/81, checked exhaustively offline), double buffered: tile q+1 arrives by LDS-DMA
+//                one 1 KiB piece per wave per tap while phase q computes; weights [128 co][128 B] per (phase, tap) in
+//                a 3-deep ring (slot ^ (co>>1)&7), two pieces per wave per tap, issued three taps ahead
+//   sync       : one barrier per tap, placed before the tap's LAST k-step: it publishes chunk c+1 (s_waitcnt vmcnt(N),
+//                N counted over the pieces issued since) and frees chunk c's stage, and the first fragment reads of
+//                chunk c+1 then fly under the last 4 MFMAs of chunk c; fragment reads are inline asm, one k-step ahead
+//   epilogue   : folded BN + activation, LDS transpose, 16-byte stores of whole channel rows (the 256 outputs of a
+//                workgroup are contiguous in y when the output side is 8)
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+constexpr int CD_CIN = 64, CD_COUT = 128;
+constexpr int CD_RB = CD_CIN * 2;                 // bytes per voxel row
+constexpr int CD_PIECES = 51;                     // 405 rows in 1 KiB pieces of 8 rows
+constexpr int CD_TILE = CD_PIECES * 1024;         // 52,224 B
+constexpr int CD_WST = CD_COUT * 128;             // one weight stage: 128 rows x 64 k
+constexpr int CD_NST = 3;
+constexpr int CD_RING = 2 * CD_TILE;
+constexpr int CD_DUMMY = CD_RING + CD_NST * CD_WST;
+constexpr int CD_LDS = CD_DUMMY + 1024;           // 154,624 B
+constexpr int CD_SP = CD_COUT * 2 + 16;           // epilogue row pitch
+
+__global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             __bf16 *__restrict__ y, int dout_log2, unsigned x_bytes, unsigned w_bytes,
+                                                             int act) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lo = dout_log2, no = 1 << lo, li = lo + 1, n = 1 << li;
+
+    // XCD-aware order: consecutive boxes (same sample) run on one XCD and share its L2
+    const int nwg = gridDim.x;
+    int blk = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bxw = no >> 3, bxh = no >> 3, bxd = no >> 2;
+    const int bw = blk % bxw; blk /= bxw;
+    const int bh = blk % bxh; blk /= bxh;
+    const int bd = blk % bxd; const int b = blk / bxd;
+    const int od0 = bd * 4, oh0 = bh * 8, ow0 = bw * 8;
+
+    const u32x4 rsx = make_rsrc(x, x_bytes), rsw = make_rsrc(w, w_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // ---- producers
+    auto issue_x = [&](int q, int slot) {            // slot = 0..6: piece slot*8 + wave of phase q into tile[q & 1]
+        const int piece = slot * 8 + wave;
+        const int rl = piece * 8 + (lane >> 3);
+        const int zd = rl / 81, rem = rl - zd * 81, jh = rem / 9, jw = rem - jh * 9;
+        const int g = (lane & 7) ^ (jw & 7);
+        const int id = 2 * (od0 + zd) + ((q >> 2) & 1) - 1, ih = 2 * (oh0 + jh) + ((q >> 1) & 1) - 1, iw = 2 * (ow0 + jw) + (q & 1) - 1;
+        const bool ok = q < 8 && rl < 405 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+        const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * CD_RB + g * 16 : 0xFFFFFFF0u;
+        const unsigned dst = piece < CD_PIECES ? lds0 + (q & 1) * CD_TILE + piece * 1024 : lds0 + CD_DUMMY;
+        dma16(rsx, vo, dst);
+    };
+    auto issue_w = [&](int c) {                      // chunk c = q*8 + a into ring[c % 3]: rows 16*wave .. 16*wave+15
+        const int q = c >> 3, a = c & 7;
+        const int td = 2 * ((a >> 2) & 1) + ((q >> 2) & 1), th = 2 * ((a >> 1) & 1) + ((q >> 1) & 1), tw = 2 * (a & 1) + (q & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        const unsigned st = lds0 + CD_RING + (c % CD_NST) * CD_WST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned vo = c < 64 ? (unsigned)row * (64 * CD_RB) + t * CD_RB + g * 16 : 0xFFFFFFF0u;
+            dma16(rsw, vo, st + (wave * 2 + i) * 1024);
+        }
+    };
+
+    // ---- prologue: phase 0 tile, weight chunks 0..2
+#pragma unroll 1
+    for (int s = 0; s < 7; ++s) issue_x(0, s);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- consumer addressing (LDS byte addresses)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int rl0 = wm * 81 + (fr >> 3) * 9 + (fr & 7);
+    unsigned xo[2][4], wo[4];                      // inside tile 0 / weight stage 0
+#pragma unroll
+    for (int aw = 0; aw < 2; ++aw)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xo[aw][ks] = lds0 + rl0 * CD_RB + (((ks * 2 + fh) ^ (((fr & 7) + aw) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = lds0 + CD_RING + (wn * 64 + fr) * 128 + (((ks * 2 + fh) ^ ((fr >> 1) & 7)) << 4);
+
+    f32x16 acc[2][2];                              // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // Fragment sets P and Q = {x row tile 0, x row tile 1, w channel tile 0, w channel tile 1}.  The reads are inline
+    // asm so that the set for k-step s+1 is in flight while the MFMAs of k-step s run (left to the scheduler, the
+    // reads sink to just before their use and every k-step exposes the LDS latency); LDS returns in order, so
+    // lgkmcnt(4) = "everything but the 4 reads just issued".
+#define CD_LDFRAG(F, XA, XOFF, WA)                                                                                              \
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:4096" \
+                 : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3])                                                           \
+                 : "v"(XA), "v"(WA), "n"(XOFF), "n"((XOFF) + 4 * 9 * CD_RB)                                                    \
+                 : "memory")
+#define CD_WAITFRAG(F, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) : "n"(N) : "memory")
+#define CD_MFMA4(F)                                                                                                             \
+    do {                                                                                                                        \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                       \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&F[2 + nt]),                \
+                                                                  *reinterpret_cast<const bf16x8 *>(&F[mt]), acc[nt][mt], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    } while (0)
+
+    u32x4 P[4], Q[4];
+    CD_LDFRAG(P, xo[0][0], 0, wo[0]);              // chunk 0, k-step 0
+
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const unsigned tsel = (q & 1) * CD_TILE, tnext = ((q + 1) & 1) * CD_TILE;
+        auto tap = [&](auto a_c) {
+            constexpr int A = decltype(a_c)::value;
+            constexpr int AW = A & 1, TO = (((A >> 2) & 1) * 81 + ((A >> 1) & 1) * 9 + AW) * CD_RB;
+            constexpr int AN = (A + 1) & 7, AWN = AN & 1, TON = (((AN >> 2) & 1) * 81 + ((AN >> 1) & 1) * 9 + AWN) * CD_RB;
+            const int c = q * 8 + A;
+            const unsigned wsel = (c % CD_NST) * CD_WST, wnext = ((c + 1) % CD_NST) * CD_WST;
+            CD_LDFRAG(Q, xo[AW][1] + tsel, TO, wo[1] + wsel);
+            CD_WAITFRAG(P, 4);
+            CD_MFMA4(P);
+            CD_LDFRAG(P, xo[AW][2] + tsel, TO, wo[2] + wsel);
+            CD_WAITFRAG(Q, 4);
+            CD_MFMA4(Q);
+            CD_LDFRAG(Q, xo[AW][3] + tsel, TO, wo[3] + wsel);
+            CD_WAITFRAG(P, 4);
+            CD_MFMA4(P);
+            CD_WAITFRAG(Q, 0);                     // every LDS read of chunk c has returned: its stage may be refilled
+            // chunk c+1's weights (and, before tap 0 of the next phase, the whole next tile) have landed.  Pieces issued
+            // after w(c+1): [x piece of tap A-1] w(c+2) x2; tap 7 needs the x piece of tap 6, which precedes w(c+2).
+            wait_vm<(A == 0 || A == 7) ? 2 : 3>();
+            __syncthreads();
+            if (A < 7) issue_x(q + 1, A);
+            issue_w(c + 3);
+            CD_LDFRAG(P, xo[AWN][0] + (A == 7 ? tnext : tsel), TON, wo[0] + wnext);
+            CD_MFMA4(Q);
+        };
+        tap(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 1>{});
+        tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{});
+        tap(std::integral_constant<int, 4>{});
+        tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{});
+        tap(std::integral_constant<int, 7>{});
+    }
+    CD_WAITFRAG(P, 0);                              // the look-ahead reads of the non-existent chunk 64
+    wait_vm<0>();                                   // trailing zero-fill pieces still target LDS
+    __syncthreads();
+
+    // ---- epilogue: lane = output (wm, mt, fr); registers walk channels
+    char *stage = smem;
+    auto fill = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = wn * 64 + nt * 32 + 8 * g + 4 * fh;
+                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c);
+                    if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c);
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[nt][mt][4 * g + e] * sc[e] + sh[e];
+                        if (ACT == VV_ACT_ELU) t = t > 0.f ? t : __expf(t) - 1.f;
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        o[e] = static_cast<__bf16>(t);
+                    }
+                    *reinterpret_cast<bf16x4 *>(stage + (wm * 64 + mt * 32 + fr) * CD_SP + c * 2) = o;
+                }
+    };
+    switch (act) {
+        case VV_ACT_ELU: fill(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: fill(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: fill(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: fill(std::integral_constant<int, VV_ACT_NONE>{}); break;
+    }
+    __syncthreads();
+    constexpr int CPR = CD_COUT * 2 / 16;             // 16-byte chunks per output row
+#pragma unroll
+    for (int i = 0; i < 256 * CPR / 512; ++i) {
+        const int id = tid + 512 * i, r = id / CPR, cc = id % CPR;
+        const int od = od0 + (r >> 6), oh = oh0 + ((r >> 3) & 7), ow = ow0 + (r & 7);
+        const size_t vox = ((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (CD_COUT * 2) + cc * 16) =
+            *reinterpret_cast<const uint4 *>(stage + r * CD_SP + cc * 16);
+    }
+}
+
+}  // namespace
+
+VV_EXPORT int vv_conv3d_k4s2_direct_supported(int side, int cin, int cout, int dtype) {
+    return dtype == VV_BF16 && cin == CD_CIN && cout == CD_COUT && side >= 16 && vv_is_pow2(side);
+}
+
+VV_EXPORT int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                        int batch, int side, int cin, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_packed || !y) return VV_ERR_NULL;
+    if (!vv_conv3d_k4s2_direct_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_packed) || !vv_aligned16(y)) return VV_ERR_ALIGN;
+    const size_t xb = (size_t)batch * side * side * side * cin * 2;
+    if (xb >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
+    const int so = side / 2;
+    const int boxes = (so / 4) * (so / 8) * (so / 8);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+        return true;
+    }();
+    (void)attr;
+    VV_LAUNCH(conv_direct_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
+              reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, reinterpret_cast<__bf16 *>(y),
+              vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act);
+    return vv_launch_status();
+}

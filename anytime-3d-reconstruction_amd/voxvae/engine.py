@@ -188,11 +188,15 @@ class EncoderEngine(_EngineBase):
         self._call('E1', 'vv_conv3d_first_fwd', L.ptr(x), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
                L.ptr(h), B, D, f[0], self.act, self.dt, st)
         for i in range(1, len(f) - 1):
-            nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt)
-            ws = self.ws.get(nb)
             o = self._empty(B, side // 2, side // 2, side // 2, f[i])
-            self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
-                   L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+            if not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
+                self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+            else:
+                nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt)
+                ws = self.ws.get(nb)
+                self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                           L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
             h, side = o, side // 2
         i = len(f) - 1
         K = side ** 3 * f[i - 1]

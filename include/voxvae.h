@@ -87,6 +87,14 @@ int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale,
                         int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* Direct variant of vv_conv3d_k4s2_fwd for the widest encoder layer (bf16, Cin 64 -> Cout 128, side >= 16): per input
+ * phase q (x index parity per axis) the layer is a k2 s1 convolution over the phase sub-grid, so a 4x8x8 box of
+ * outputs stages 8 phase tiles of 5x9x9 voxels in LDS instead of 64 im2col tiles; same vv_pack_conv_k4 weights.
+ * vv_conv3d_k4s2_direct_supported() says whether a shape is covered (callers fall back to vv_conv3d_k4s2_fwd). */
+int vv_conv3d_k4s2_direct_supported(int side, int cin, int cout, int dtype);
+int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                              int batch, int side, int cin, int cout, int act, int dtype, void *stream);
+
 /* Direct variant of vv_convT3d_k4s2_fwd for the widest decoder layer (bf16, Cin 128 -> Cout 64, side >= 8): the input
  * halo tile of a 4x4x8 block of cells is staged in LDS once and serves all 8 parities x 8 taps; weights come from the
  * MFMA-fragment-ordered panel of vv_pack_convT_k4s2_frag ([8 parity][8 tap][Cin/16][Cout/32][64 lanes][8]).

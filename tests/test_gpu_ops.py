@@ -251,3 +251,36 @@ def test_convT3d_k4s2_direct(L, B, side):
     L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(xd), L.ptr(wf), L.ptr(scd), L.ptr(shd), L.ptr(y), B, side, cin, cout, 1, L.VV_BF16, _st())
     torch.cuda.synchronize()
     _check(y, ref, 'bf16', 'convT3d_k4s2_direct')
+
+
+@pytest.mark.parametrize('B,side,act', [(2, 16, 1), (1, 32, 1), (3, 16, 0), (5, 16, 2)])
+def test_conv3d_k4s2_direct(L, B, side, act):
+    """LDS-resident phase-tile variant of the widest encoder layer (bf16, 64 -> 128); also bit-compared with the
+    implicit-GEMM kernel's result on the same inputs (same bf16 operands, different summation order)."""
+    cin, cout = 64, 128
+    assert L.load().vv_conv3d_k4s2_direct_supported(side, cin, cout, L.VV_BF16) == 1
+    assert L.load().vv_conv3d_k4s2_direct_supported(8, cin, cout, L.VV_BF16) == 0
+    assert L.load().vv_conv3d_k4s2_direct_supported(side, cin, cout, L.VV_F32) == 0
+    rng = np.random.default_rng(side + 10 * B)
+    x = _bf16_round(rng.standard_normal((B, side, side, side, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cin, cout)) / np.sqrt(64 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    actname = {0: 'none', 1: 'elu', 2: 'relu'}[act]
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, actname)
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(cout, 64 * cin, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(wd), L.ptr(wp), cin, cout, L.VV_BF16, _st())
+    so = side // 2
+    y = torch.full((B, so, so, so, cout), -7.0, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, side, cin, cout, act, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'conv3d_k4s2_direct')
+    nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, cin, cout, L.VV_BF16)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    y2 = torch.empty_like(y)
+    L.call('vv_conv3d_k4s2_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y2), B, side, cin, cout, act, L.VV_BF16,
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= 2e-2, 'direct vs implicit-GEMM: %.3e' % d
