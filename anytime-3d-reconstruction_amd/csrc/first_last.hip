@@ -1,6 +1,10 @@
 // The HBM-bound tail of the path (gfx950):
 //   final_bce  : Conv3DTranspose k4 s2 SAME -> 1 channel, sigmoid, weighted BCE and TP/FP/FN, fused
 //                (autoencoder3D.py:129-136; function.py:73-82, 100-115)
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -365,6 +369,147 @@ __global__ __launch_bounds__(256) void first_conv_bf16_kernel(const float *__res
     }
 }
 
+// first_conv, plane form (bf16, 32 <= D <= 256): one work item = 256 outputs of ONE output plane (all D/2 columns x
+// 512/D rows) x 64 channels.  Its input is 4 consecutive occupancy planes (2 od - 1 .. 2 od + 2), full-width rows: a
+// single contiguous stream of float4 loads per item (the gather form above re-reads every voxel 8x as scattered dwords).
+// The planes are kept in LDS as bf16 with a one-voxel left pad, S[c + 1] = x[c], so that dword j of a row holds
+// (x[2j-1], x[2j]): the 4 taps tw = 0..3 of output column ow are dwords ow, ow+1 -- the MFMA B fragment of a lane
+// (k = 16 td + 8 fh + j  <->  th = 2 fh + (j>>2), tw = j&3) is two 8-byte LDS reads, and no im2col tile is ever written.
+// Weights (64 x 64 taps) live in registers as A fragments for the whole persistent loop; the next item's planes are in
+// flight (registers) while the current item multiplies, transposes through LDS and stores its contiguous 32 KiB.
+template <int NI>
+__global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               __bf16 *__restrict__ y, int batch, int din_log2, int act, int items_per_wg) {
+    constexpr int COUT = 64, EPITCH = COUT * 2;            // output rows are 8 chunks of 16 B, chunk ^ (row & 7)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = din_log2, D = 1 << li, lo = li - 1, OW = 1 << lo;
+    const int loh = 8 - lo, OH = 1 << loh;                 // output rows per item
+    const int R = 2 * OH + 2, PD = (D >> 1) + 2, PP = R * PD;   // tile rows per plane, dwords per row / per plane
+    unsigned *tile = reinterpret_cast<unsigned *>(smem);   // [4][R][PD] dwords of bf16 pairs
+    char *stage = smem + ((4 * PP * 4 + 15) & ~15);        // [256][EPITCH]
+    float *ss = reinterpret_cast<float *>(stage + 256 * EPITCH);   // folded BN: scale[64], shift[64]
+    uint4 *wl = reinterpret_cast<uint4 *>(ss + 128);       // weights as A fragments [ks][nt][lane]
+    if (tid < 64) ss[tid] = scale ? scale[tid] : 1.f;
+    else if (tid < 128) ss[tid] = shift ? shift[tid - 64] : 0.f;
+    const int hblocks = OW >> loh;                         // items per output plane
+    const long nitems = (long)batch * OW * hblocks;
+
+    // ---- per-thread load slots (the same for every item): slot s = tid + 256 i -> (plane, tile row, float4 column)
+    const int qpr = D >> 2, lq = li - 2;                   // float4 per row
+    const int nslots = 4 * R * qpr;
+    int sp[NI], srr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int s = tid + 256 * i, row = s >> lq;        // row = plane * R + rr
+        sp[i] = s < nslots ? row / R : -1;
+        srr[i] = row - (s < nslots ? row / R : 0) * R;
+    }
+    const int m4 = tid & (qpr - 1);                        // float4 column (256 % qpr == 0)
+
+    // ---- weights as A fragments: [ks][nt], lane (co = nt*32 + lane&31, k = ks*16 + 8*(lane>>5) + j)
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int i = wave; i < 8; i += 4)                      // i = ks*2 + nt
+        wl[i * 64 + lane] = *reinterpret_cast<const uint4 *>(wp + ((i & 1) * 32 + fr) * 64 + (i >> 1) * 16 + 8 * fh);
+
+    float4 raw[NI];
+    auto fetch = [&](long item) {
+        const int hb = (int)(item % hblocks);
+        const long t = item / hblocks;
+        const int od = (int)(t & (OW - 1));
+        const long b = t >> lo;
+        const int d0 = 2 * od - 1, h0 = 2 * hb * OH - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = d0 + sp[i], ih = h0 + srr[i];
+            const bool ok = sp[i] >= 0 && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)D;
+            raw[i] = ok ? *reinterpret_cast<const float4 *>(x + ((((b << li) + id) << li) + ih << li) + 4 * m4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto pack2 = [](float a, float b) -> unsigned {
+        const __bf16 ha = static_cast<__bf16>(a), hb = static_cast<__bf16>(b);
+        return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+    };
+
+    const long item0 = (long)blockIdx.x * items_per_wg;
+    const long item_end = item0 + items_per_wg < nitems ? item0 + items_per_wg : nitems;
+    if (item0 < item_end) fetch(item0);
+    auto run = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    for (long item = item0; item < item_end; ++item) {
+        // ---- planes -> LDS (bf16 pairs, left pad)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float left = __shfl_up(raw[i].w, 1);
+            if (m4 == 0) left = 0.f;
+            if (sp[i] >= 0) {
+                unsigned *dst = tile + (sp[i] * R + srr[i]) * PD + 2 * m4;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(pack2(left, raw[i].x), pack2(raw[i].y, raw[i].z));
+                if (m4 == qpr - 1) dst[2] = pack2(raw[i].w, 0.f);
+            }
+        }
+        __syncthreads();
+        if (item + 1 < item_end) fetch(item + 1);
+
+        // one 32-output row tile at a time (2 x 16 accumulator registers live): 8 MFMAs, then its epilogue
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 acc[2];                                  // [nt]
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+            const int o = (wave * 2 + mt) * 32 + fr, ohl = o >> lo, ow = o & (OW - 1);
+            const unsigned *t0 = tile + (2 * ohl + 2 * fh) * PD + ow;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const unsigned *t1 = t0 + ks * PP;
+                const uint4 xf = make_uint4(t1[0], t1[1], t1[PD], t1[PD + 1]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 wf = wl[(ks * 2 + nt) * 64 + lane];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wf),
+                                                                      *reinterpret_cast<const bf16x8 *>(&xf), acc[nt], 0, 0, 0);
+                }
+            }
+            // folded BN + activation, transpose through LDS
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = nt * 32 + 8 * g + 4 * fh;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[nt][4 * g + e] * sc[e] + sh[e];
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        ov[e] = static_cast<__bf16>(t);
+                    }
+                    *reinterpret_cast<bf16x4 *>(stage + o * EPITCH + ((((c >> 3) ^ o) & 7) << 4) + (c & 4) * 2) = ov;
+                }
+        }
+        __syncthreads();
+        char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2);     // the item's 256 outputs are contiguous in y
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, rl = idx >> 3, c = idx & 7;
+            *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 7) << 4));
+        }
+    }
+    };
+    switch (act) {
+        case VV_ACT_ELU: run(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: run(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: run(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: run(std::integral_constant<int, VV_ACT_NONE>{}); break;
+    }
+}
+
 __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nblk) {
     const int b = blockIdx.x, lane = threadIdx.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -412,6 +557,23 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
 int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,
                               int side, int act, void *stream) {
     const int li = vv_log2(side);
+    if (side >= 32 && side <= 256 && !getenv("VV_FIRSTCONV_GATHER")) {
+        const int ow = side / 2, oh = 256 / ow, r = 2 * oh + 2, pd = side / 2 + 2;
+        const long nitems = (long)batch * ow * (ow / oh);
+        const size_t lds = (((size_t)4 * r * pd * 4 + 15) & ~(size_t)15) + 256 * (64 * 2) + 128 * sizeof(float) + 8 * 64 * 16;
+        const int nslots = 4 * r * (side / 4), ni = (nslots + 255) / 256;
+        static const long maxwg = getenv("VV_FIRSTCONV_WGS") ? atol(getenv("VV_FIRSTCONV_WGS")) : 256 * 3;
+        const int ipw = (int)((nitems + maxwg - 1) / maxwg);
+        const int grid = (int)((nitems + ipw - 1) / ipw);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        if (ni <= 5)
+            VV_LAUNCH((first_conv_plane_kernel<5>), dim3(grid), dim3(256), lds, st, x, reinterpret_cast<const __bf16 *>(w_packed), scale, shift,
+                      reinterpret_cast<__bf16 *>(y), batch, li, act, ipw);
+        else
+            VV_LAUNCH((first_conv_plane_kernel<6>), dim3(grid), dim3(256), lds, st, x, reinterpret_cast<const __bf16 *>(w_packed), scale, shift,
+                      reinterpret_cast<__bf16 *>(y), batch, li, act, ipw);
+        return vv_launch_status();
+    }
     const long M = (long)batch << (3 * (li - 1));
     const int ntiles = (int)((M + 127) / 128);
     const int grid = ntiles < 2048 ? ntiles : 2048;

@@ -122,7 +122,8 @@ def test_dense(L, dtname, M, N, K):
 
 
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,D', [(2, 32), (1, 16), (3, 8)])
+# D >= 32 (bf16) takes the plane-form kernel, smaller grids the gather form; B = 7 leaves a ragged last workgroup
+@pytest.mark.parametrize('B,D', [(2, 32), (1, 16), (3, 8), (7, 32), (1, 64), (1, 128)])
 def test_conv3d_first(L, dtname, B, D):
     from voxvae import synthetic as syn
     rng = np.random.default_rng(D)
