@@ -197,6 +197,24 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
 
     // ---- epilogue: lane = output (wm, mt, fr); registers walk channels
     char *stage = smem;
+    // folded BN quads of this lane's 32 channels, fetched as one batch (two uniform branches, one wait)
+    f32x4 scv[2][4], shv[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { scv[nt][g] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (scale) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) scv[nt][g] = *reinterpret_cast<const f32x4 *>(scale + wn * 64 + nt * 32 + 8 * g + 4 * fh);
+    }
+    if (shift) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) shv[nt][g] = *reinterpret_cast<const f32x4 *>(shift + wn * 64 + nt * 32 + 8 * g + 4 * fh);
+    }
     auto fill = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
@@ -206,14 +224,12 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = wn * 64 + nt * 32 + 8 * g + 4 * fh;
-                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c);
-                    if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c);
+                    const f32x4 sc = scv[nt][g], sh = shv[nt][g];
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[nt][mt][4 * g + e] * sc[e] + sh[e];
-                        if (ACT == VV_ACT_ELU) t = t > 0.f ? t : __expf(t) - 1.f;
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
                         else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                         else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
                         o[e] = static_cast<__bf16>(t);

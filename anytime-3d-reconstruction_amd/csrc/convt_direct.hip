@@ -170,7 +170,25 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
             load_group(G + 6, b2); compute_group(g + 3, b3);
         }
 
-        // ---- epilogue of this parity: lane = cell (mt, mh, mw), registers walk channels
+        // ---- epilogue of this parity: lane = cell (mt, mh, mw), registers walk channels.  The folded BN quads are
+        // fetched as one batch (two uniform branches, one wait) rather than quad by quad.
+        f32x4 scv[NT][4], shv[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { scv[nt][g] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (scale) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) scv[nt][g] = *reinterpret_cast<const f32x4 *>(scale + nt * 32 + 8 * g + 4 * fh);
+        }
+        if (shift) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) shv[nt][g] = *reinterpret_cast<const f32x4 *>(shift + nt * 32 + 8 * g + 4 * fh);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -178,14 +196,12 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = nt * 32 + 8 * g + 4 * fh;
-                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                    if (scale) sc = *reinterpret_cast<const f32x4 *>(scale + c);
-                    if (shift) sh = *reinterpret_cast<const f32x4 *>(shift + c);
+                    const f32x4 sc = scv[nt][g], sh = shv[nt][g];
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
-                        if (ACT == VV_ACT_ELU) t = t > 0.f ? t : __expf(t) - 1.f;
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
                         else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                         else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
                         o[e] = static_cast<__bf16>(t);

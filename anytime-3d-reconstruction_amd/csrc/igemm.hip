@@ -447,6 +447,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int okind = a.partial ? 2 : (a.out_bf16 ? 0 : 1);
     const int es = okind == 0 ? 2 : 4;
     const int pitch = BN * es + 16;
+    // Folded BN quads of this lane's channels, fetched as one batch (two uniform branches, one wait) instead of a
+    // dependent load + wait per quad.
+    f32x4 scv[TN][4], shv[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { scv[j][g] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[j][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (okind != 2 && a.scale) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * (BN / 2) + j * 32 + 8 * g + 4 * fh;
+                if (n0 + cl < a.N) scv[j][g] = *reinterpret_cast<const f32x4 *>(a.scale + n0 + cl);
+            }
+    }
+    if (okind != 2 && a.shift) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * (BN / 2) + j * 32 + 8 * g + 4 * fh;
+                if (n0 + cl < a.N) shv[j][g] = *reinterpret_cast<const f32x4 *>(a.shift + n0 + cl);
+            }
+    }
     auto fill = [&](auto act_c, auto kind_c) {
         constexpr int ACT = decltype(act_c)::value, KIND = decltype(kind_c)::value;
 #pragma unroll
@@ -454,11 +479,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wn * (BN / 2) + j * 32 + 8 * g + 4 * fh;   // tile-local channel of the quad
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (KIND != 2 && n0 + cl < a.N) {
-                    if (a.scale) sc = *reinterpret_cast<const f32x4 *>(a.scale + n0 + cl);
-                    if (a.shift) sh = *reinterpret_cast<const f32x4 *>(a.shift + n0 + cl);
-                }
+                const f32x4 sc = scv[j][g], sh = shv[j][g];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int rl = wm * (BM / 2) + i * 32 + fr;
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                         float t = acc[i][j][4 * g + e];
                         if (KIND != 2) {
                             t = t * sc[e] + sh[e];
-                            if (ACT == VV_ACT_ELU) t = t > 0.f ? t : (KIND == 0 ? __expf(t) - 1.f : expm1f(t));
+                            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = KIND == 0 ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
                             else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                             else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
                         }
