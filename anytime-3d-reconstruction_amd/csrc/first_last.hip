@@ -260,6 +260,167 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// final_bce, sweep form (bf16): the box kernel above stages a 6^3 halo for 4^3 cells, so it loads, multiplies and
+// publishes every input voxel 3.4 times.  Here one workgroup owns an 8 x 8 tile of cells in (h, w) and sweeps the whole
+// depth: per plane d it stages the 10 x 10 halo rows ONCE (LDS-DMA, double buffered), forms P_d = X_d W^T on MFMA, keeps
+// the td in {2,3} half of P_d for the next step and combines the td in {0,1} half with the kept half of P_{d-1}:
+//   od = 2d - 1 + s  <-  P_d[td = s] + P_{d-1}[td = 2 + s]            (s = 0, 1; 2 x 2 terms in h, w each)
+// so a step finishes two output planes of 16 x 16 voxels (256 threads x one pw pair).  Amplification 1.56 (h, w halo
+// only), P is published once per cell, and the four BCE / TP / FP / FN sums stay in registers for the whole sweep.
+// The voxel math uses the hardware exp / log / rcp (relative error ~1e-7, far below the bf16 operand rounding) and
+// thresholds on the logit (sigmoid(l) >= 0.5 <=> l >= 0, function.py:110).
+constexpr int SW_ROWS = 100, SW_XB = 13 * 1024, SW_NX = 2, SW_PP = 36, SW_PSZ = 100 * SW_PP;   // X slot bytes (104 rows); P row pitch / buffer floats
+constexpr int SW_LDS = SW_NX * SW_XB + 1024 + 24 * 128 + 3 * SW_PSZ * 4;
+
+__global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                                 const float *__restrict__ target, float *__restrict__ probs,
+                                                                 float *__restrict__ logits, float *__restrict__ partials,
+                                                                 int din_log2, unsigned x_bytes, float gamma, float epsilon) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Xs = smem;                                             // ring of SW_NX planes x [104 rows][128 B], slot-swizzled; 1 KiB sink; 24 spare rows
+    float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024 + 24 * 128);   // P_d[td 0,1]      [100][36]
+    float *PH = PL + SW_PSZ;                                     // P_d / P_{d-1}[td 2,3]  [2][100][33]
+    __shared__ float red[4][4];
+    const int li = din_log2, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
+    const int T = gridDim.x;
+    const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
+    const int tile = wi % ntile, b = wi / ntile;
+    const int h0 = (tile / nt8) * 8, w0 = (tile % nt8) * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    fm_u32x4 rs;
+    {
+        const unsigned long long base = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
+        rs[2] = __builtin_amdgcn_readfirstlane(x_bytes);
+        rs[3] = 0x00020000u;
+    }
+    const unsigned ldsx = (unsigned)(unsigned long long)(fm_lptr_t)Xs;
+    // plane d -> ring slot d % 3: 13 pieces of 8 rows; every wave issues 4 (the 3 surplus ones go to the sink so that the
+    // vector-memory counter advances uniformly); rows >= 100, voxels outside the grid and planes outside [0, n) arrive
+    // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
+    // the slot: whatever it finds there only reaches accumulator rows >= 104, which are never published.
+    auto stage = [&](int d) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
+            const int zh = row / 10, zw = row - zh * 10;
+            const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+            const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
+            fm_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
+        }
+    };
+    stage(0);
+
+    // weights of this wave's tap half as B fragments (lane: tap nt*32 + fr, k = ks*16 + 8 fh + j), straight from the
+    // Keras array [64 taps][64 ci]
+    const int nt = wv & 1, mt0 = wv >> 1;
+    uint4 fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const float *wr = w + (nt * 32 + fr) * FB_CIN + ks * 16 + 8 * fh;
+        const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wr), w1v = *reinterpret_cast<const f32x4 *>(wr + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = static_cast<__bf16>(w0v[e]); o[4 + e] = static_cast<__bf16>(w1v[e]); }
+        fb[ks] = *reinterpret_cast<const uint4 *>(&o);
+    }
+    for (int i = tid; i < SW_PSZ; i += 256) PH[i] = 0.f;         // P_{-1} = 0
+
+    // gather role: s = od parity slot, ohh = output row inside the tile, mw = cell column (both pw per lane)
+    const int mw = tid & 7, ohh = (tid >> 3) & 15, sl = tid >> 7;
+    const int mh = ohh >> 1, ph = ohh & 1;
+    const int lo = li + 1, n2 = 2 * n;
+    const int oh = 2 * h0 + ohh, ow = 2 * (w0 + mw);
+    const float hi = 1.0f - epsilon;
+    float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    int oldh = 0;
+
+#pragma unroll 1
+    for (int d = 0; d <= n; ++d) {
+        const int od = 2 * d - 1 + sl;
+        const bool ovalid = (unsigned)od < (unsigned)n2;
+        const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
+        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
+        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
+        // plane d+1 issued right after it -- the look-ahead.  In flight, oldest first:
+        //   [plane d x4][stores d-1] [y d][plane d+1 x4]
+        // so "all but the newest 5" covers plane d whatever the number of stores (more stores only wait for more).
+        float2 y;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
+        stage(d + 1);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d (issued a step ago) has landed
+        __syncthreads();                                         // ... for every wave; previous gather finished
+
+        const char *Xd = Xs + (d % SW_NX) * SW_XB;
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+            const int mt = mt0 + 2 * j;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 fa = *reinterpret_cast<const uint4 *>(Xd + fm_lds_off(mt * 32 + fr, ks * 2 + fh));
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
+                                                                 *reinterpret_cast<const bf16x8 *>(&fa), acc[j], 0, 0, 0);   // D[tap][cell]
+            }
+        }
+        // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
+        // of one (td, th): one 16-byte store per quad
+        float *Pw = nt == 0 ? PL : PH + (oldh ^ 1) * SW_PSZ;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (mt0 + 2 * j) * 32 + fr;
+            if (row < SW_ROWS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4 *>(Pw + row * SW_PP + 8 * g + 4 * fh) =
+                        f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            }
+        }
+        __syncthreads();
+
+        float l0 = 0.f, l1 = 0.f;
+        const float *Pold = PH + oldh * SW_PSZ;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {
+            const int zh = mh + ph - ah + 1, th = 1 - ph + 2 * ah;
+            const int off = (zh * 10 + mw) * SW_PP + (sl * 4 + th) * 4;
+            const float *r0 = PL + off, *r1 = Pold + off;
+            l0 += r0[SW_PP + 1] + r0[3] + r1[SW_PP + 1] + r1[3];                         // pw = 0
+            l1 += r0[2 * SW_PP] + r0[SW_PP + 2] + r1[2 * SW_PP] + r1[SW_PP + 2];   // pw = 1
+        }
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+1 may still be in flight
+        if (ovalid) {
+            const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
+            float p[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                p[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-l[e]));
+                const float q = fminf(fmaxf(p[e], epsilon), hi);
+                bce -= gamma * yy[e] * __logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * __logf(1.0f - q);
+                const float yh = l[e] >= 0.f ? 1.f : 0.f;
+                tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
+            }
+            if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+            if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+        }
+        oldh ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
+    bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
+    if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
+    __syncthreads();
+    if (tid < 4) partials[((size_t)b * ntile + tile) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 __device__ float vv_zero_word = 0.f;
 
 // first_conv (bf16): Conv3D k4 s2 SAME with ONE input channel -- a [rows x 64 taps] x [64 x 64] product per 128-row
@@ -542,6 +703,21 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     const int nb = side / 4, nblk = nb * nb * nb;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *partials = reinterpret_cast<float *>(workspace);
+    const int ntile = (side / 8) * (side / 8);
+    const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "box": override the batch heuristic (tests)
+    const bool sweep = dtype == VV_BF16 && side >= 8 &&
+                       (force ? force[0] == 's' : (long)batch * ntile >= 128);   // enough workgroups to fill the chip
+    if (sweep) {
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&final_bce_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+            return true;
+        }();
+        (void)attr;
+        VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * batch), dim3(256), SW_LDS, st, reinterpret_cast<const __bf16 *>(x), w_keras, target,
+                  probs, logits, partials, vv_log2(side), (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
+        VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, ntile);
+        return vv_launch_status();
+    }
     if (dtype == VV_BF16)
         VV_LAUNCH(final_bce_mfma_kernel, dim3(nblk * batch), dim3(256), (size_t)FM_ROWS * 128 + 64 * 128, st,
                   reinterpret_cast<const __bf16 *>(x), w_keras, target, probs, logits, partials, vv_log2(side),

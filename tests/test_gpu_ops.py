@@ -147,8 +147,13 @@ def test_conv3d_first(L, dtname, B, D):
 
 
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,side', [(2, 16), (3, 4), (1, 8)])
-def test_convT3d_final_bce(L, dtname, B, side):
+@pytest.mark.parametrize('B,side,form', [(2, 16, 'box'), (3, 4, 'box'), (1, 8, 'box'), (2, 16, 'sweep'), (3, 8, 'sweep'), (1, 32, 'sweep')])
+def test_convT3d_final_bce(L, dtname, B, side, form, monkeypatch):
+    # bf16 has two kernels: 'box' (4^3 cells + halo per workgroup, small batches) and 'sweep' (8x8 tile swept through
+    # the depth, large batches); VV_FINAL_BCE overrides the batch heuristic so both are checked at test sizes
+    if dtname == 'f32' and form == 'sweep':
+        pytest.skip('sweep form is bf16 only')
+    monkeypatch.setenv('VV_FINAL_BCE', form)
     rng = np.random.default_rng(side)
     dt, tdt = L.DTYPES[dtname], (torch.float32 if dtname == 'f32' else torch.bfloat16)
     x = rng.standard_normal((B, side, side, side, 64)).astype(np.float32)
