@@ -568,8 +568,9 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     const int bk = dtype == VV_BF16 ? 64 : 32;
     const int nchunks = (K + bk - 1) / bk;
     const long tiles = (long)((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn) * p.nparity;
+    static const long target = getenv("VV_SPLIT_TARGET") ? atol(getenv("VV_SPLIT_TARGET")) : 512;
     int split = 1;
-    while (tiles * split < 512 && split * 2 <= nchunks / 8 && split < 64) split *= 2;
+    while (tiles * split < target && split * 2 <= nchunks / 8 && split < 64) split *= 2;
     p.cps = (nchunks + split - 1) / split;
     p.split = (nchunks + p.cps - 1) / p.cps;
     p.ws_bytes = p.split > 1 ? (size_t)p.split * p.nparity * M * N * sizeof(float) : 0;

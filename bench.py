@@ -13,6 +13,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` 
 the timed region) and `cpu_baseline` (the fp32 C oracle, rank 0 at N=1 only, bounded sample).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -122,7 +123,8 @@ def main():
 
     cfg = syn.make_config(a.voxel, a.latent, True)
     ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
-    model = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    with contextlib.redirect_stdout(sys.stderr):      # the model classes print build messages like the reference's; stdout carries ONE JSON line
+        model = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
     model._encoder.set_weights_dict(ep)
     model._decoder.set_weights_dict(dp)
     xh = syn.make_voxels(a.batch, a.voxel, seed=1234 + rank)
