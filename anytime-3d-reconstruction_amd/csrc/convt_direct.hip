@@ -138,29 +138,57 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[mt][nt][q] = 0.f;
 
-        auto compute_group = [&](int g, const uint4 *bf) {   // g = tap*GPT + part
-            const int a = g / GPT, ad = (a >> 2) & 1, ah = (a >> 1) & 1, aw = a & 1;
+        // A fragments come from the resident tile by inline-asm ds_read_b128, ONE k-step ahead of the MFMAs that use
+        // them (set P/Q ping-pong): left to the scheduler the reads sink to just before their use and every k-step
+        // exposes the LDS latency.  LDS returns in order, so lgkmcnt(MT) = "all but the MT reads just issued".
+        const unsigned tile_lds = (unsigned)(unsigned long long)(lptr_t)tile;
+        auto a_addr = [&](int a, int ks) -> unsigned {
+            const int ad = (a >> 2) & 1, ah = (a >> 1) & 1, aw = a & 1;
             const int zh = mh + ph - ah + 1, zw = mw + pw - aw + 1;
             const int sw = (zw + 8 * zh) & 15;
-            const char *vrow = tile + (((pd - ad + 1) * HH + zh) * HW + zw) * RB;   // + md * HH * HW * RB per row tile
-            uint4 fa[2][MT];
-            auto read_a = [&](int k, uint4 *dst) {
-                const int slot = ((((g % GPT) * HALF + k) * 2 + fh) ^ sw) * 16;
+            return tile_lds + (((pd - ad + 1) * HH + zh) * HW + zw) * RB + (((ks * 2 + fh) ^ sw) << 4);
+        };
+        u32x4 fP[MT], fQ[MT];
+        auto ld = [&](u32x4 *F, unsigned addr) {
+            if constexpr (MT == 2)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"
+                             : "=&v"(F[0]), "=&v"(F[1]) : "v"(addr), "n"(HH * HW * RB) : "memory");
+            else
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7"
+                             : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3])
+                             : "v"(addr), "n"(HH * HW * RB), "n"(2 * HH * HW * RB), "n"(3 * HH * HW * RB) : "memory");
+        };
+        auto wait = [&](u32x4 *F) {
+            if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(F[0]), "+v"(F[1]) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) : : "memory");
+        };
+        auto mma = [&](const u32x4 *F, const uint4 *bfk) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const uint4 *>(vrow + mt * (HH * HW * RB) + slot);
-            };
-            read_a(0, fa[0]);
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int k = 0; k < HALF; ++k) {
-                if (k + 1 < HALF) read_a(k + 1, fa[(k + 1) & 1]);       // one k-step ahead of the MFMAs that use it
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&bfk[nt]),
+                                                                          *reinterpret_cast<const bf16x8 *>(&F[mt]), acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // one group = HALF k-steps of one tap with the weights of ring buffer bf; k-steps alternate P, Q (HALF is even)
+        static_assert(HALF % 2 == 0, "P/Q roles must line up across groups");
+        auto compute_group = [&](int g, const uint4 *bf) {
+            const int a = g / GPT, part = g % GPT;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&bf[k * NT + nt]),
-                                                                              *reinterpret_cast<const bf16x8 *>(&fa[k & 1][mt]), acc[mt][nt], 0, 0, 0);
+            for (int k = 0; k < HALF; k += 2) {
+                const int ks = part * HALF + k;
+                ld(fQ, a_addr(a, ks + 1));
+                wait(fP);
+                mma(fP, bf + k * NT);
+                // the k-step after next: same tap, or the first of the next tap (wraps harmlessly after the last one)
+                const int ks2 = ks + 2;
+                ld(fP, ks2 < KS ? a_addr(a, ks2) : a_addr((a + 1) & 7, 0));
+                wait(fQ);
+                mma(fQ, bf + (k + 1) * NT);
             }
         };
+        ld(fP, a_addr(0, 0));
 #pragma unroll 1
         for (int g = 0; g < GPP; g += 4) {
             const int G = pi * GPP + g;
@@ -169,6 +197,8 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
             load_group(G + 5, b1); compute_group(g + 2, b2);
             load_group(G + 6, b2); compute_group(g + 3, b3);
         }
+        if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fP[0]), "+v"(fP[1]) : : "memory");   // the wrapped look-ahead read
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fP[0]), "+v"(fP[1]), "+v"(fP[2]), "+v"(fP[3]) : : "memory");
 
         // ---- epilogue of this parity: lane = cell (mt, mh, mw), registers walk channels.  The folded BN quads are
         // fetched as one batch (two uniform branches, one wait) rather than quad by quad.

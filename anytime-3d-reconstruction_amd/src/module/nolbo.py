@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 import src.net_core.autoencoder3D as ae3D
+import src.net_core.darknet as darknet
 from voxvae import engine as _E
 from voxvae import lib as _L
 from voxvae.tensor import DeviceArray, as_device_f32
@@ -245,15 +246,16 @@ class nolboSingleObject_modelnet_category_VAE(_ModelnetBase):
 
 
 class nolboSingleObject_VAE(_ModelnetBase):
-    """Voxel half of the reference's image -> 3D model, nolbo.py:750-982 (BASELINE.json configs[2], test_pascal_VAE_dr.py):
-    decoder3D + losses + latent masking / prior correction + modality dropout run on the HIP path exactly as in the
-    modelnet classes (the reference's getEval bodies are line-for-line the same algorithm, nolbo.py:856-928 vs 1449-1528).
+    """The reference's image -> 3D model, nolbo.py:750-982 (BASELINE.json configs[2], test_pascal_VAE_dr.py): decoder3D +
+    losses + latent masking / prior correction + modality dropout run on the HIP path exactly as in the modelnet classes
+    (the reference's getEval bodies are line-for-line the same algorithm, nolbo.py:856-928 vs 1449-1528).
 
-    The 2D image encoder (Darknet19 backbone + head2D, reference src/net_core/darknet.py) is OUT OF SCOPE of the voxel
-    hot path: pass it as `encoder_backbone` -- any callable images -> head output [B, 2*z_dim]
-    (numpy / torch / DeviceArray).  With no backbone the `input_images` are taken to BE head outputs [B, 2*z_dim]
-    (synthetic head features).  fit() trains the decoder only through this class; the 2D encoder's
-    training stays with whatever framework provides it."""
+    The 2D image encoder is outside the voxel hot path and runs on stock PyTorch ops:
+    `backbone_style=darknet.Darknet19` builds the backbone and, as the reference does (nolbo.py:775-783), a `head2D` on
+    top of it from `nolbo_structure['encoder_head']`; any other callable images -> features works as `encoder_backbone`.
+    With neither, `input_images` are taken to BE head outputs [B, 2*z_dim] (synthetic head features, SURVEY §8d
+    config 3).  fit() (nolbo.py:786-833) trains all three: the decoder step runs on the HIP path and hands back
+    d loss / d head-output, which continues through the 2D encoder by torch autograd (f32 models only)."""
     _variational = True
 
     def __init__(self, nolbo_structure,
@@ -275,18 +277,34 @@ class nolboSingleObject_VAE(_ModelnetBase):
 
     def _buildModel(self):
         print('build Models...')
-        if self._encoder_backbone is None and self._backbone_style is not None:
-            self._encoder_backbone = self._backbone_style(name=self._enc_backbone_str['name'])
         # ==============set decoder3D
         self._decoder = ae3D.decoder3D(structure=self._dec_str)
         self._dec_eng = self._decoder._engine
         self._device = self._dec_eng.device
         self._act_dt = self._dec_eng.dt
+        if self._encoder_backbone is None and self._backbone_style is not None:
+            self._encoder_backbone = self._backbone_style(name=self._enc_backbone_str['name'], device=self._device)
+        # ==============set encoder head (nolbo.py:775-783)
+        self._encoder_head = None
+        if self._encoder_backbone is not None and self._enc_head_str is not None and hasattr(self._encoder_backbone, 'output_shape'):
+            self._encoder_head = darknet.head2D(name=self._enc_head_str['name'],
+                                                input_shape=self._encoder_backbone.output_shape[1:],
+                                                output_dim=self._enc_head_str['output_dim'],
+                                                filter_num_list=self._enc_head_str['filter_num_list'],
+                                                filter_size_list=self._enc_head_str['filter_size_list'],
+                                                last_pooling='max', activation=self._enc_head_str['activation'],
+                                                device=self._device)
+        self._trainer2d = None
         print('done')
 
+    def _encoder_2d(self, x, training=False):
+        if self._encoder_backbone is None:
+            return x
+        f = self._encoder_backbone(x, training=training) if self._encoder_head is not None else self._encoder_backbone(x)
+        return self._encoder_head(f, training=training) if self._encoder_head is not None else f
+
     def _encode_latent(self, x, eps=None, want_kl=False):
-        enc_out = x if self._encoder_backbone is None else self._encoder_backbone(x)
-        enc_out = self._dev(enc_out)
+        enc_out = self._dev(self._encoder_2d(x, training=False))
         Lz = self._latent_dim
         if enc_out.dim() != 2 or enc_out.shape[1] != 2 * Lz:
             raise ValueError('the 2D encoder must emit [B, %d] (mean | logVar), got %s' % (2 * Lz, tuple(enc_out.shape)))
@@ -299,17 +317,65 @@ class nolboSingleObject_VAE(_ModelnetBase):
             a = a.numpy()
         return as_device_f32(a, self._device)
 
-    def fit(self, inputs):
-        raise NotImplementedError('nolboSingleObject_VAE.fit needs the 2D Darknet encoder (out of the voxel hot-path scope)')
+    def fit(self, inputs, _eps=None, _dropout=None):
+        """nolbo.py:786-833: (input_images, output_images) -> (loss_kl, loss_shape, pr, rc).  total = KL + shape + the l2
+        terms of the 2D head; Adam(learning_rate) on backbone + head (torch) and decoder (HIP)."""
+        from voxvae import train as _T
+        input_images, output_images = inputs
+        y = self._dev(output_images)
+        if self._trainer2d is None:
+            self._trainer2d = _T.Trainer(None, self._dec_eng, variational=True, learning_rate=self._learning_rate)
+            mods = [m for m in (self._encoder_backbone, self._encoder_head) if isinstance(m, torch.nn.Module)]
+            params = [p for m in mods for p in m.parameters()]
+            self._opt2d = torch.optim.Adam(params, lr=self._learning_rate, eps=1e-7) if params else None   # Keras epsilon
+        trainable_2d = self._opt2d is not None
+        enc_out = self._encoder_2d(input_images, training=True) if trainable_2d else self._dev(self._encoder_2d(input_images))
+        B, Lz = enc_out.shape[0], self._latent_dim
+        eps = torch.randn(B, Lz, dtype=torch.float32, device=self._device) if _eps is None else self._dev(_eps)
+        drop_mask, drop_scale = None, 1.0
+        if self._dropout:
+            rate, keep = _dropout if _dropout is not None else (float(np.random.rand()), None)
+            keep = (torch.rand(B, Lz, device=self._device) >= rate).float() if keep is None else self._dev(keep)
+            drop_mask, drop_scale = keep, 1.0 / (1.0 - rate)
+        kl, stats, metrics, de = self._trainer2d.step_from_latent(enc_out.detach().contiguous(), y, eps, drop_mask, drop_scale)
+        if trainable_2d:
+            self._opt2d.zero_grad(set_to_none=True)
+            reg = [l for m in (self._encoder_head, self._encoder_backbone) if hasattr(m, 'losses') for l in m.losses]
+            enc_out.backward(de, retain_graph=bool(reg))
+            if reg:
+                torch.stack(reg).sum().backward()
+            self._opt2d.step()
+        m = metrics.cpu().numpy()
+        return float(kl.mean().item()), float(m[0]), float(m[1]), float(m[2])
+
+    def saveEncoderBackbone(self, save_path):
+        if hasattr(self._encoder_backbone, 'save_weights'):
+            self._encoder_backbone.save_weights(os.path.join(save_path, self._enc_backbone_str['name']))
+
+    def saveEncoderHead(self, save_path):
+        if self._encoder_head is not None:
+            self._encoder_head.save_weights(os.path.join(save_path, self._enc_head_str['name']))
 
     def saveEncoder(self, save_path):
-        pass   # the 2D encoder is not owned by this class
+        self.saveEncoderBackbone(save_path)
+        self.saveEncoderHead(save_path)
+
+    def loadEncoderBackbone(self, load_path, file_name=None):
+        if hasattr(self._encoder_backbone, 'load_weights'):
+            self._encoder_backbone.load_weights(os.path.join(load_path, file_name or self._enc_backbone_str['name']))
+
+    def loadEncoderHead(self, load_path, file_name=None):
+        if self._encoder_head is not None:
+            self._encoder_head.load_weights(os.path.join(load_path, file_name or self._enc_head_str['name']))
 
     def loadEncoder(self, load_path, file_name=None):
-        pass
+        self.loadEncoderBackbone(load_path)
+        self.loadEncoderHead(load_path)
 
     def saveModel(self, save_path):
+        self.saveEncoder(save_path=save_path)
         self.saveDecoder(save_path=save_path)
 
     def loadModel(self, load_path):
+        self.loadEncoder(load_path=load_path)
         self.loadDecoder(load_path=load_path)

@@ -70,15 +70,15 @@ class _BN:
 
 class Trainer:
     def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None):
-        if enc.dt != L.VV_F32 or dec.dt != L.VV_F32:
+        if (enc is not None and enc.dt != L.VV_F32) or dec.dt != L.VV_F32:
             raise NotImplementedError("training runs in 'f32' (exact-f32 MFMA) this round; build the model with dtype 'f32'")
-        self.enc, self.dec, self.var, self.lr = enc, dec, variational, float(learning_rate)
-        self.dev = enc.device
+        self.enc, self.dec, self.var, self.lr = enc, dec, variational, float(learning_rate)   # enc None: decoder-only (image -> 3D model)
+        self.dev = dec.device
         self.world, self.group = int(world_size), group
         self.t = 0
         self.debug = None          # set to a dict to capture intermediate tensors of the next step (tests)
         self.ws = E._Workspace(self.dev)
-        names = [('enc/' + k, v.shape) for k, v in enc.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
+        names = [] if enc is None else [('enc/' + k, v.shape) for k, v in enc.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         names += [('dec/' + k, v.shape) for k, v in dec.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         # backward order: decoder tail first ... encoder head last
         self.order = list(reversed(names))
@@ -134,16 +134,30 @@ class Trainer:
     # ------------------------------------------------------------------ one step
     def step(self, x, y, eps=None, drop_mask=None, drop_scale=1.0):
         """x, y: float32 CUDA [B,D,D,D,1].  Returns device tensors (loss_kl or None, stats [B,4], metrics [4])."""
-        enc, dec, dev = self.enc, self.dec, self.dev
-        enc.ensure_packed()
-        dec.ensure_packed()
-        B, D = x.shape[0], enc.D
-        fe, fd = enc.filters, dec.filters
-        act = enc.act
+        self.enc.ensure_packed()
+        self.dec.ensure_packed()
+        B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
-        st = _st()
-        f32 = L.VV_F32
+        enc_out, est = self._encoder_forward(x, B)
+        kl, stats, metrics, de = self._latent_decoder(enc_out, y, eps, drop_mask, drop_scale, B, inv_gb)
+        self._encoder_backward(x, de, est, B)
+        self._apply()
+        return kl, stats, metrics
 
+    def step_from_latent(self, enc_out, y, eps=None, drop_mask=None, drop_scale=1.0):
+        """Decoder-only step for the image -> 3D model (nolbo.py:786-833): enc_out [B, 2L] (mean | logVar) comes from a 2D
+        encoder owned by the caller.  Trains the decoder and returns (loss_kl, stats, metrics, d total / d enc_out) so the
+        caller can continue the backward pass through its own encoder."""
+        self.dec.ensure_packed()
+        B = enc_out.shape[0]
+        inv_gb = 1.0 / float(B * self.world)
+        kl, stats, metrics, de = self._latent_decoder(enc_out, y, eps, drop_mask, drop_scale, B, inv_gb)
+        self._apply()
+        return kl, stats, metrics, de
+
+    def _encoder_forward(self, x, B):
+        enc, st, f32 = self.enc, _st(), L.VV_F32
+        D, fe, act = enc.D, enc.filters, enc.act
         # ---------------- encoder forward (raw conv -> batch stats -> BN + act)
         ec, eh, ebn = [], [], []
         side = D // 2
@@ -162,8 +176,11 @@ class Trainer:
         ne = len(fe) - 1
         K5 = side ** 3 * fe[ne - 1]
         enc_out = self._dense(eh[-1], enc.packed['w%d' % ne], B, fe[ne], K5)
-        Sside_e = side
+        return enc_out, (ec, eh, ebn, side, K5)
 
+    def _latent_decoder(self, enc_out, y, eps, drop_mask, drop_scale, B, inv_gb):
+        dec, dev, st, f32 = self.dec, self.dev, _st(), L.VV_F32
+        D, fd, act = dec.D, dec.filters, dec.act
         # ---------------- latent
         Lz = dec.L
         if self.var:
@@ -243,6 +260,16 @@ class Trainer:
                    inv_gb, st)
         else:
             de = dz
+        if self.debug is not None:
+            self.debug.update({'dlogit': dlogit, 'probs': probs, 'enc_out': enc_out, 'z': z, 'dz': dz, 'de': de, 'c_d0': c_d0,
+                               't0': t0, 'dt0': dt0, 'h_dec': dh_, 'c_dec': dc_})
+        return kl, stats, metrics, de
+
+    def _encoder_backward(self, x, de, est, B):
+        enc, st, f32 = self.enc, _st(), L.VV_F32
+        D, fe, act = enc.D, enc.filters, enc.act
+        ec, eh, ebn, Sside_e, K5 = est
+        ne = len(fe) - 1
         # ---------------- backward: encoder
         E_out = fe[ne]
         dpanel = self._empty(E_out, K5)
@@ -265,12 +292,12 @@ class Trainer:
             side *= 2
         dcv = self._bn_bwd(ec[0], dh, ebn[0], B * side ** 3, 'enc/bn0/gamma', 'enc/bn0/beta', act)
         self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0])
-
         if self.debug is not None:
-            self.debug.update({'dlogit': dlogit, 'probs': probs, 'enc_out': enc_out, 'z': z, 'dz': dz, 'de': de, 'c_d0': c_d0,
-                               't0': t0, 'dt0': dt0, 'h_dec': dh_, 'c_dec': dc_, 'h_enc': eh, 'c_enc': ec})
+            self.debug.update({'h_enc': eh, 'c_enc': ec})
 
+    def _apply(self):
         # ---------------- cross-rank gradient sum, then Adam on every replica
+        st = _st()
         self.grads.all_reduce(self.group)
         self.t += 1
         lr_t = self.lr * (1.0 - ADAM_B2 ** self.t) ** 0.5 / (1.0 - ADAM_B1 ** self.t)
@@ -278,6 +305,6 @@ class Trainer:
             p = self._p(name)
             L.call('vv_adam_step', L.ptr(p), L.ptr(self._g(name)), L.ptr(self.m[name]), L.ptr(self.v[name]), p.numel(), lr_t,
                    ADAM_B1, ADAM_B2, ADAM_EPS, st)
-        enc._dirty = True
-        dec._dirty = True
-        return kl, stats, metrics
+        if self.enc is not None:
+            self.enc._dirty = True
+        self.dec._dirty = True

@@ -213,3 +213,47 @@ def test_pascal_vae_decoder_half_config3():
         assert abs(float(out[loss_i]) - bce.mean()) < 0.02 * bce.mean()
         assert abs(float(out[pr_i]) - pr) < 5e-3 and abs(float(out[rc_i]) - rc) < 5e-3
     np.testing.assert_allclose(np.array(m._z_category_corrected), zc, atol=2e-5)
+
+
+def test_pascal_image_to_3d_end_to_end(tmp_path):
+    """Darknet19 + head2D (stock PyTorch ops) in front of the HIP decoder -- getEval with missing
+    latents, fit() through both halves, checkpoints, and the two entry scripts on synthetic (image, voxel) pairs."""
+    sys.path.insert(0, PKG)
+    import voxvae
+    voxvae.set_default_dtype('f32')
+    import src.module.nolbo as nolbo
+    import src.net_core.darknet as darknet
+    import src.dataset_loader.pascal3D as pascal3D
+    import test_pascal_VAE_dr as te
+    import train_pascal_VAE_dr as tr
+    from voxvae import synthetic as syn
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = te.make_config(16, 32)
+    m = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg, backbone_style=darknet.Darknet19, learning_rate=1e-3, dropout=True)
+    ld = pascal3D.dataLoaderSingleObject('train', 'synthetic:8:32')
+    _, cls, _, _, img, vox = ld.getNextBatch(4, (64, 64), augmentation=False)
+    cats = syn.make_category_vectors(12, 16)
+    out = m.getEval(inputs=(img, vox, cls), category_vectors=cats, missing_prob=0.5)
+    assert len(out) == 10 and np.array(out[0]).shape == (4, 32, 32, 32, 1) and all(np.isfinite(float(v)) for v in out[1:5])
+    w_dec = m._decoder._engine.params['convT1/kernel'].clone()
+    w_bb = m._encoder_backbone.layers[0].conv.weight.detach().clone()
+    w_hd = m._encoder_head.last.weight.detach().clone()
+    l0 = m.fit(inputs=(img, vox))
+    assert len(l0) == 4 and all(np.isfinite(l0))
+    for _ in range(4):
+        l1 = m.fit(inputs=(img, vox))
+    assert l1[1] < l0[1]                                                       # shape loss falls on a repeated batch
+    assert not torch.equal(w_dec, m._decoder._engine.params['convT1/kernel'])
+    assert not torch.equal(w_bb, m._encoder_backbone.layers[0].conv.weight) and not torch.equal(w_hd, m._encoder_head.last.weight)
+    m.saveModel(str(tmp_path))
+    m2 = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg, backbone_style=darknet.Darknet19)
+    m2.loadModel(str(tmp_path))
+    eps = syn.make_eps(4, 16)
+    a = m.getEval(inputs=(img, vox), _eps=eps)
+    b = m2.getEval(inputs=(img, vox), _eps=eps)
+    np.testing.assert_allclose(np.array(a[0]), np.array(b[0]), atol=1e-6)
+    l8 = te.train(config=cfg, load_path=str(tmp_path), missing_pr=0.9, batch_size=4, image_size=(64, 64), max_iter=2, dataset_path='synthetic:8:32')
+    assert l8.shape == (8,) and np.all(np.isfinite(l8))
+    res = tr.train(training_epoch=1, config=cfg, batch_size=4, image_size=(64, 64), max_iter=2, dataset_path='synthetic:8:32')
+    assert all(np.all(np.isfinite(r)) for r in res)

@@ -79,3 +79,25 @@ def test_two_steps_loss_decreases_and_state_advances():
     assert model._trainer.t == 6
     assert l1[1] < l0[1], (l0, l1)          # same batch, 6 Adam steps at lr 1e-3: the shape loss must go down
     assert all(np.isfinite(l1))
+
+
+def test_decoder_only_step_matches_full_step():
+    """Trainer.step_from_latent (image -> 3D model, nolbo.py:786-833) is the decoder + latent part of the full step: fed
+    the full step's encoder output it must produce the same decoder gradients and the same d loss / d enc_out."""
+    from voxvae import train as T
+    cfg, ep, dp, model, x, eps = _setup(32, 64, True, 4)
+    xd = torch.from_numpy(x).to(DEV)
+    epsd = torch.from_numpy(eps).to(DEV)
+    full = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-3)
+    full.debug = {}
+    full.step(xd, xd, epsd)
+    enc_out, de = full.debug['enc_out'].clone(), full.debug['de'].clone()
+    g_full = {n: full.grads.views[n].clone() for n, _ in full.order if n.startswith('dec/')}
+    model._decoder.set_weights_dict(dp)                     # undo the Adam update of the full step
+    half = T.Trainer(None, model._dec_eng, True, 1e-3)
+    kl, stats, metrics, de2 = half.step_from_latent(enc_out, xd, epsd)
+    torch.cuda.synchronize()
+    assert torch.equal(de, de2)
+    assert [n for n, _ in half.order] == [n for n, _ in full.order if n.startswith('dec/')]
+    for n, g in g_full.items():
+        assert torch.equal(g, half.grads.views[n]), n

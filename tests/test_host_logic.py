@@ -127,3 +127,38 @@ def test_adam_rule_of_training_oracle():
     big = np.abs(g) > 1e-4 * np.abs(g).max()
     np.testing.assert_allclose(step[big], -1e-3 * np.sign(g[big]), rtol=2e-2)
     assert r['adam']['t'] == 1
+
+
+def test_darknet19_and_head2d_shapes_and_keras_attributes():
+    """src/net_core/darknet.py mirror (reference darknet.py:83-173), CPU torch: 5 ceil-mode poolings (MaxPool2D 'same'),
+    1024 output channels, head = 1x1 conv + max pool to [B, output_dim], l2 terms only on the head's kernels."""
+    import src.net_core.darknet as darknet
+    bb = darknet.Darknet19(name='bb', device='cpu')
+    assert bb.output_shape == (None, None, None, 1024)
+    x = np.random.default_rng(0).random((2, 72, 40, 3)).astype('float32')
+    f = bb(x)
+    assert tuple(f.shape) == (2, 3, 2, 1024)                     # ceil(72/32), ceil(40/32)
+    assert len([m for m in bb.modules() if m.__class__.__name__ == '_ConvBNAct']) == 18 and bb.losses == []
+    hd = darknet.head2D('hd', bb.output_shape[1:], 32, [64], [3], last_pooling='max', device='cpu')
+    o = hd(f)
+    assert tuple(o.shape) == (2, 32) and not o.requires_grad
+    assert len(hd.losses) == 2 and abs(float(hd.losses[1]) - 0.0005 * float((hd.last.weight ** 2).sum())) < 1e-9
+    o2 = hd(bb(x, training=True), training=True)
+    assert o2.requires_grad and len(bb.trainable_variables) == 18 * 3
+    # BatchNormalization defaults of Keras: epsilon 1e-3, momentum 0.99 (torch momentum 0.01)
+    bn = bb.layers[0].bn
+    assert bn.eps == 1e-3 and bn.momentum == 0.01
+
+
+def test_pascal_synthetic_loader_contract():
+    import src.dataset_loader.pascal3D as pascal3D
+    ld = pascal3D.dataLoaderSingleObject(trainOrVal='val', Pascal3DDataPath='synthetic:10:16')
+    inst, cls, s, c, img, vox = ld.getNextBatch(batchSizeof3DShape=4, imageSize=(48, 32), augmentation=False)
+    assert img.shape == (4, 32, 48, 3) and img.dtype == np.float32 and vox.shape == (4, 16, 16, 16, 1)
+    assert cls.shape == (4, 12) and np.all(cls.sum(1) == 1) and set(np.unique(vox)) <= {0.0, 1.0}
+    np.testing.assert_allclose(s ** 2 + c ** 2, 1.0, atol=1e-6)
+    for _ in range(2):
+        ld.getNextBatch(batchSizeof3DShape=4, imageSize=(48, 32), augmentation=False)
+    assert ld.epoch == 1 and ld.dataLength == 10
+    with pytest.raises(FileNotFoundError):
+        pascal3D.dataLoaderSingleObject(Pascal3DDataPath='/nonexistent')
