@@ -142,6 +142,33 @@ __global__ void sampling_kernel(const float *__restrict__ mu, const float *__res
     if (i < n) out[i] = mu[i] + sqrtf(expf(logvar[i])) * eps[i];
 }
 
+// regulizer_loss (function.py:40-71): out[i] = sum_j same(i,j) * hinge(sum_l |m_i - m_j| / exp(0.5 lv_i) - dist)^2 with
+// hinge(d) = d > 0 ? 0 : d; same(i,j) = 1 when the class rows are identical (or no class input).  One workgroup per i.
+__global__ __launch_bounds__(256) void regulizer_loss_kernel(const float *__restrict__ mean, const float *__restrict__ logvar,
+                                                             const float *__restrict__ cls, float dist, float *__restrict__ out,
+                                                             int batch, int latent, int cdim) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int j = tid; j < batch; j += 256) {
+        float d = 0.f;
+        for (int l = 0; l < latent; ++l)
+            d += fabsf(mean[(size_t)i * latent + l] - mean[(size_t)j * latent + l]) / expf(0.5f * logvar[(size_t)i * latent + l]);
+        d -= dist;
+        float v = d > 0.f ? 0.f : d * d;
+        if (cls) {
+            float cd = 0.f;
+            for (int c = 0; c < cdim; ++c) cd += fabsf(cls[(size_t)i * cdim + c] - cls[(size_t)j * cdim + c]);
+            if (cd > 0.f) v = 0.f;
+        }
+        acc += v;
+    }
+    acc = vv_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) out[i] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace
 
 VV_EXPORT int vv_latent_mask_fill(const float *z, const float *mask, const float *prototypes, int classes, float *z_out,
@@ -206,6 +233,15 @@ VV_EXPORT int vv_voxel_precision_recall(const float *target, const float *pred, 
     if (batch <= 0 || voxels <= 0) return VV_ERR_SHAPE;
     VV_LAUNCH(precision_recall_kernel, dim3(batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), target, pred,
                        prob, tp, fp, fn, voxels);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_regulizer_loss(const float *mean, const float *logvar, const float *class_input, float dist_in_z_space,
+                                float *out, int batch, int latent, int class_dim, void *stream) {
+    if (!mean || !logvar || !out) return VV_ERR_NULL;
+    if (batch <= 0 || latent <= 0 || (class_input && class_dim <= 0)) return VV_ERR_SHAPE;
+    VV_LAUNCH(regulizer_loss_kernel, dim3(batch), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mean, logvar, class_input,
+              dist_in_z_space, out, batch, latent, class_dim);
     return vv_launch_status();
 }
 

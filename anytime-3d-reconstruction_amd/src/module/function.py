@@ -1,4 +1,4 @@
-"""Drop-in for the loss/latent ops of the reference's src/module/function.py (lines 35-38, 73-115), each a
+"""Drop-in for the loss/latent ops of the reference's src/module/function.py (lines 35-38, 40-71, 73-115), each a
 hand-written HIP kernel behind the C ABI (include/voxvae.h).  Same names, argument order and meaning:
 note that binary_loss takes (xPred, xTarget) while voxelPrecisionRecall takes (xTarget, xPred), and that
 xPred is a PROBABILITY in both, exactly as in the reference.  Inputs may be numpy arrays, DeviceArrays or
@@ -48,6 +48,18 @@ def kl_loss(mean, logVar, mean_target, logVar_target):
     B, Lz = m.shape[0], m.numel() // m.shape[0]
     out = torch.empty(B, dtype=torch.float32, device=m.device)
     _L.call('vv_kl_loss', _L.ptr(m), _L.ptr(lv), _L.ptr(mt), _L.ptr(lvt), _L.ptr(out), B, Lz, _st())
+    return DeviceArray(out)
+
+
+def regulizer_loss(z_mean, z_logVar, dist_in_z_space, class_input=None):
+    """reference function.py:40-71 -> [B]: pairwise hinge that keeps latent means at least `dist_in_z_space` apart
+    (scaled L1), optionally only between samples of the same class."""
+    m, lv = _dev(z_mean), _dev(z_logVar)
+    B, Lz = m.shape[0], m.numel() // m.shape[0]
+    c = None if class_input is None else _dev(class_input)
+    out = torch.empty(B, dtype=torch.float32, device=m.device)
+    _L.call('vv_regulizer_loss', _L.ptr(m), _L.ptr(lv), _L.ptr(c), float(dist_in_z_space), _L.ptr(out), B, Lz,
+            0 if c is None else c.numel() // B, _st())
     return DeviceArray(out)
 
 

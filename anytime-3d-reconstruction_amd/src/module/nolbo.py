@@ -22,6 +22,7 @@ import torch
 
 import src.net_core.autoencoder3D as ae3D
 import src.net_core.darknet as darknet
+import src.net_core.priornet as priornet
 from voxvae import engine as _E
 from voxvae import lib as _L
 from voxvae.tensor import DeviceArray, as_device_f32
@@ -379,3 +380,95 @@ class nolboSingleObject_VAE(_ModelnetBase):
     def loadModel(self, load_path):
         self.loadEncoder(load_path=load_path)
         self.loadDecoder(load_path=load_path)
+
+
+class nolboSingleObject_modelnet_category_only(_ModelnetBase):
+    """reference nolbo.py:1594-1787: the VAE with a learned class-conditional prior.  Encoder, decoder, losses and the
+    missing-latent correction run on the HIP path as in nolboSingleObject_modelnet_category_VAE -- getEval is that class's
+    getEval with the prototype table replaced by the prior network's means over `category_indices` (nolbo.py:1685-1688).
+    The prior network (a 40 -> ... -> L MLP, src/net_core/priornet.py) and the [B, L] latent algebra of fit() -- KL to the
+    learned prior, prior / posterior mixing, the pairwise regulariser -- are outside the voxel path (SURVEY §8(f)
+    rank 2) and run as torch autograd code between the HIP encoder and decoder (voxvae.train.Trainer.step_custom_latent)."""
+    _variational = True
+
+    def __init__(self, nolbo_structure,
+                 learning_rate=1e-4):
+        self._enc_backbone_str = nolbo_structure
+        self._enc_str = nolbo_structure['encoder']
+        self._dec_str = nolbo_structure['decoder']
+        self._prior_class_str = nolbo_structure['prior_class']
+        self._dropout = False
+        self._learning_rate = learning_rate
+        self._buildModel()
+        # ==============set prior network
+        self._priornet_class = priornet.priornet(structure=self._prior_class_str, device=self._device)
+        self._trainer_c = None
+
+    def fit(self, inputs, dropout=False, *, _rand=None):
+        """nolbo.py:1620-1676: (x, y, onehot) -> (loss_kl, loss_shape, loss_reg, pr, rc); total = KL(q || prior) + shape +
+        0.01 reg.  `_rand` (tests) = dict(eps, eps_prior, mix (bool), noise [B,L], drop_rate, drop_keep [B,L])."""
+        from voxvae import train as _T
+        input_images, output_images, category_list = inputs
+        x, y, onehot = self._dev(input_images), self._dev(output_images), self._dev(category_list)
+        B, Lz = x.shape[0], self._latent_dim
+        if self._trainer_c is None:
+            self._trainer_c = _T.Trainer(self._enc_eng, self._dec_eng, variational=False, learning_rate=self._learning_rate)
+            self._opt_prior = torch.optim.Adam(self._priornet_class.parameters(), lr=self._learning_rate, eps=1e-7)
+        r = _rand or {}
+        dev = self._device
+        eps = self._dev(r['eps']) if 'eps' in r else torch.randn(B, Lz, device=dev)
+        eps_p = self._dev(r['eps_prior']) if 'eps_prior' in r else torch.randn(B, Lz, device=dev)
+        mix = bool(r['mix']) if 'mix' in r else not (np.random.rand() > 0.5)       # :1642: z itself with probability 1/2
+        noise = None
+        if mix:
+            missing_pr = 0.3
+            noise = self._dev(r['noise']) if 'noise' in r else self._dev(
+                np.random.choice(a=[True, False], size=(B, Lz), p=[1. - missing_pr, missing_pr]).astype('float32'))
+        drop = None
+        if dropout:
+            rate = float(r.get('drop_rate', np.random.rand()))
+            keep = self._dev(r['drop_keep']) if 'drop_keep' in r else (torch.rand(B, Lz, device=dev) >= rate).float()
+            drop = (keep, 1.0 / (1.0 - rate))
+        dist = 2.0 * Lz
+
+        def latent(enc_out):
+            mean_p, lv_p = self._priornet_class(onehot, training=True)
+            mean, lv = enc_out[:, :Lz], torch.clamp(enc_out[:, Lz:2 * Lz], -10.0, 10.0)
+            z = mean + torch.sqrt(torch.exp(lv)) * eps                               # function.py:35-38
+            z_prior = mean_p + torch.sqrt(torch.exp(lv_p)) * eps_p
+            z_in = z if noise is None else torch.where(noise == 1., z, z_prior)
+            if drop is not None:
+                z_in = z_in * drop[0] * drop[1]
+            kl = (0.5 * (lv_p - lv) + (torch.exp(lv) + (mean - mean_p) ** 2) / (2.0 * torch.exp(lv_p)) - 0.5).sum(-1).mean()   # function.py:84-98
+            d = (torch.abs(mean_p[:, None, :] - mean_p[None, :, :]) / torch.exp(0.5 * lv_p)[:, None, :]).sum(-1) - dist
+            reg = torch.where(d > 0, torch.zeros_like(d), d * d).sum(-1).mean()      # function.py:40-71, no class input (:1663)
+            return z_in, kl + 0.01 * reg, (kl.detach(), reg.detach())
+
+        self._opt_prior.zero_grad(set_to_none=True)
+        stats, m, (kl, reg) = self._trainer_c.step_custom_latent(x, y, latent)
+        self._opt_prior.step()
+        return DeviceArray(kl), DeviceArray(m[0]), DeviceArray(reg), DeviceArray(m[1]), DeviceArray(m[2])
+
+    def getEval(self, inputs, category_indices=np.identity(40), training=False, missing_prob=0.0, *, _eps=None, _mask=None, _eps2=None):
+        """nolbo.py:1678-1754 -> the 10-tuple of the VAE class, classified / corrected against the prior means."""
+        if training:
+            raise NotImplementedError('getEval(training=True) is not used by any reference caller')
+        mean_prior, _ = self._priornet_class(np.asarray(category_indices, dtype='float32'), training=False)
+        return _ModelnetBase.getEval(self, inputs, category_vectors=mean_prior.detach().contiguous(), missing_prob=missing_prob,
+                                     _eps=_eps, _mask=_mask, _eps2=_eps2)
+
+    def savePriorCategory(self, save_path):
+        self._priornet_class.save_weights(os.path.join(save_path, self._prior_class_str['name']))
+
+    def loadPriorCategory(self, load_path, file_name=None):
+        self._priornet_class.load_weights(os.path.join(load_path, file_name or self._prior_class_str['name']))
+
+    def saveModel(self, save_path):
+        self.saveEncoder(save_path=save_path)
+        self.saveDecoder(save_path=save_path)
+        self.savePriorCategory(save_path=save_path)
+
+    def loadModel(self, load_path):
+        self.loadEncoder(load_path=load_path)
+        self.loadDecoder(load_path=load_path)
+        self.loadPriorCategory(load_path=load_path)

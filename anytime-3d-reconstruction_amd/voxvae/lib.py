@@ -52,6 +52,7 @@ SIGNATURES = {
     'vv_binary_loss': (_i, [_vp, _vp, _f, _f, _f, _vp, _i, ctypes.c_long, _vp]),
     'vv_voxel_precision_recall': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, ctypes.c_long, _vp]),
     'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'vv_regulizer_loss': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'vv_bn_workspace_bytes': (_sz, [_l, _i]),
     'vv_bn_train_stats': (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

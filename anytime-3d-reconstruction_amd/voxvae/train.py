@@ -155,6 +155,28 @@ class Trainer:
         self._apply()
         return kl, stats, metrics, de
 
+    def step_custom_latent(self, x, y, latent_fn):
+        """Full step with the latent algebra supplied by the caller as torch autograd code (the class-conditional prior
+        model, nolbo.py:1620-1676: KL to a learned prior, prior / posterior mixing, pairwise regulariser).
+        latent_fn(enc_out) -> (z_input [B,L], extra_loss scalar, aux): enc_out is a leaf that requires grad; the decoder
+        runs on z_input.detach(), and d shape-loss / d z_input plus extra_loss are back-propagated through latent_fn's
+        graph to enc_out (continuing into the HIP encoder backward) and to whatever parameters latent_fn touched."""
+        if self.var:
+            raise ValueError('step_custom_latent expects a Trainer built with variational=False (the decoder input is z_input)')
+        self.enc.ensure_packed()
+        self.dec.ensure_packed()
+        B = x.shape[0]
+        inv_gb = 1.0 / float(B * self.world)
+        enc_out, est = self._encoder_forward(x, B)
+        leaf = enc_out.detach().requires_grad_(True)
+        with torch.enable_grad():
+            z_input, extra, aux = latent_fn(leaf)
+        _, stats, metrics, dz = self._latent_decoder(z_input.detach().contiguous(), y, None, None, 1.0, B, inv_gb)
+        torch.autograd.backward([z_input, extra], [dz, torch.ones_like(extra)])
+        self._encoder_backward(x, leaf.grad.contiguous(), est, B)
+        self._apply()
+        return stats, metrics, aux
+
     def _encoder_forward(self, x, B):
         enc, st, f32 = self.enc, _st(), L.VV_F32
         D, fe, act = enc.D, enc.filters, enc.act

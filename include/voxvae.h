@@ -166,6 +166,11 @@ int vv_voxel_precision_recall(const float *target, const float *pred, float prob
 /* kl_loss(mean, logVar, mean_target, logVar_target) -> [B]  (function.py:84-98). */
 int vv_kl_loss(const float *mean, const float *logvar, const float *mean_target, const float *logvar_target, float *out,
                int batch, int latent, void *stream);
+/* regulizer_loss (function.py:40-71): pairwise hinge on the scaled L1 distance of latent means,
+ * out[i] = sum_j same_class(i,j) * min(sum_l |m_i - m_j| / exp(0.5 lv_i) - dist_in_z_space, 0)^2; class_input may be
+ * NULL (every pair counts).  mean, logvar [B,L]; class_input [B,C]; out [B]. */
+int vv_regulizer_loss(const float *mean, const float *logvar, const float *class_input, float dist_in_z_space,
+                      float *out, int batch, int latent, int class_dim, void *stream);
 /* sampling(mu, logVar) = mu + sqrt(exp(logVar))*eps, eps injected  (function.py:35-38). */
 int vv_sampling(const float *mu, const float *logvar, const float *eps, float *out, long n, void *stream);
 

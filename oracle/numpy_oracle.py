@@ -285,3 +285,16 @@ def vae_get_latent(config, enc_p, x, eps, dtype=np.float64, variational=True):
         return enc_out
     mu, lv = split_mean_logvar(enc_out, config['z_category_dim'])
     return sampling(mu, lv, eps)
+
+
+def regulizer_loss(z_mean, z_logvar, dist_in_z_space, class_input=None):
+    """reference src/module/function.py:40-71 -> [B]."""
+    m, lv = np.asarray(z_mean, np.float64), np.asarray(z_logvar, np.float64)
+    diff = (np.abs(m[:, None, :] - m[None, :, :]) / np.exp(0.5 * lv)[:, None, :]).sum(-1)      # scaled by row i's log-variance
+    d = diff - dist_in_z_space
+    d = np.where(d > 0, 0.0, d ** 2)
+    if class_input is not None:
+        c = np.asarray(class_input, np.float64)
+        same = (np.abs(c[:, None, :] - c[None, :, :]).sum(-1) == 0).astype(np.float64)
+        d = d * same
+    return d.sum(-1)

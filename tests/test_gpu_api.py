@@ -257,3 +257,63 @@ def test_pascal_image_to_3d_end_to_end(tmp_path):
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
     res = tr.train(training_epoch=1, config=cfg, batch_size=4, image_size=(64, 64), max_iter=2, dataset_path='synthetic:8:32')
     assert all(np.all(np.isfinite(r)) for r in res)
+
+
+def test_regulizer_loss_op():
+    """function.regulizer_loss (reference function.py:40-71) against the numpy restatement, with and without classes."""
+    import voxvae
+    voxvae.set_default_device('cuda:0')
+    import src.module.function as F
+    rng = np.random.default_rng(5)
+    B, Lz = 37, 16
+    m, lv = rng.standard_normal((B, Lz)).astype(np.float32), rng.uniform(-1, 1, (B, Lz)).astype(np.float32)
+    oh = np.eye(5, dtype=np.float32)[rng.integers(0, 5, B)]
+    for dist, c in ((2.0 * Lz, None), (20.0, oh), (0.5, oh)):
+        got = np.array(F.regulizer_loss(m, lv, dist, class_input=c))
+        ref = no.regulizer_loss(m, lv, dist, c)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-4)
+    assert np.array(F.regulizer_loss(m, lv, 0.0)).max() == 0.0                # nothing is closer than 0
+
+
+def test_class_conditional_prior_model(tmp_path):
+    """SURVEY §8(f) rank 2, nolboSingleObject_modelnet_category_only (nolbo.py:1594-1787): getEval == the VAE class's
+    getEval against the prior network's class means; fit() trains encoder, decoder and prior; entry scripts run."""
+    sys.path.insert(0, PKG)
+    import voxvae
+    voxvae.set_default_dtype('f32')
+    import src.module.nolbo as nolbo
+    import train_modelnet_category as tr
+    import test_modelnet_category as te
+    from voxvae import synthetic as syn
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = tr.make_config(64, 16)
+    m = nolbo.nolboSingleObject_modelnet_category_only(nolbo_structure=cfg, learning_rate=1e-3)
+    ref = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    for mm in (m, ref):
+        mm._encoder.set_weights_dict(ep)
+        mm._decoder.set_weights_dict(dp)
+    B = 6
+    x, oh = syn.make_voxels(B, 16), syn.make_onehot(B, 40)
+    eps, eps2, mask = syn.make_eps(B, 64), syn.make_eps(B, 64, seed=8), syn.make_mask(B, 64, 0.5)
+    mean_prior, lv_prior = m._priornet_class(np.identity(40, dtype='float32'))
+    assert tuple(mean_prior.shape) == (40, 64) and float(lv_prior.abs().max()) == 0.0       # const_log_var 0.0
+    a = m.getEval(inputs=(x, x, oh), missing_prob=0.5, _eps=eps, _mask=mask, _eps2=eps2)
+    b = ref.getEval(inputs=(x, x, oh), category_vectors=mean_prior.cpu().numpy(), missing_prob=0.5, _eps=eps, _mask=mask, _eps2=eps2)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(np.array(u), np.array(v))
+    w_prior = m._priornet_class.mean[0].weight.detach().clone()
+    w_enc = m._enc_eng.params['conv1/kernel'].clone()
+    w_dec = m._dec_eng.params['convT1/kernel'].clone()
+    l0 = [float(v) for v in m.fit(inputs=(x, x, oh))]
+    assert len(l0) == 5 and all(np.isfinite(l0))
+    for _ in range(5):
+        l1 = [float(v) for v in m.fit(inputs=(x, x, oh), dropout=True)]
+    assert all(np.isfinite(l1))
+    assert not torch.equal(w_prior, m._priornet_class.mean[0].weight) and not torch.equal(w_enc, m._enc_eng.params['conv1/kernel'])
+    assert not torch.equal(w_dec, m._dec_eng.params['convT1/kernel'])
+    res = tr.train(training_epoch=1, learning_rate=1e-3, batch_size=4, config=cfg, dataset_path='synthetic:12:16', save_path=str(tmp_path), max_iter=3)
+    assert all(np.all(np.isfinite(r)) for r in res)
+    l8 = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2)
+    assert l8.shape == (8,) and np.all(np.isfinite(l8))

@@ -101,3 +101,31 @@ def test_decoder_only_step_matches_full_step():
     assert [n for n, _ in half.order] == [n for n, _ in full.order if n.startswith('dec/')]
     for n, g in g_full.items():
         assert torch.equal(g, half.grads.views[n]), n
+
+
+def test_custom_latent_step_matches_builtin_vae_step():
+    """Trainer.step_custom_latent with the plain VAE algebra written in torch (sampling + KL to N(0,1)) must reproduce
+    the built-in step (HIP reparam / KL kernels): same gradients for every parameter."""
+    from voxvae import train as T
+    cfg, ep, dp, model, x, eps = _setup(16, 64, True, 5)
+    xd, epsd = torch.from_numpy(x).to(DEV), torch.from_numpy(eps).to(DEV)
+    full = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-3)
+    full.step(xd, xd, epsd)
+    g_ref = {n: full.grads.views[n].clone() for n, _ in full.order}
+    model._encoder.set_weights_dict(ep)
+    model._decoder.set_weights_dict(dp)
+    Lz = 64
+
+    def latent(enc_out):
+        mean, lv = enc_out[:, :Lz], torch.clamp(enc_out[:, Lz:], -10.0, 10.0)
+        z = mean + torch.sqrt(torch.exp(lv)) * epsd
+        kl = (0.5 * (0.0 - lv) + (torch.exp(lv) + mean ** 2) / 2.0 - 0.5).sum(-1).mean()
+        return z, kl, None
+
+    cust = T.Trainer(model._enc_eng, model._dec_eng, False, 1e-3)
+    cust.step_custom_latent(xd, xd, latent)
+    torch.cuda.synchronize()
+    for n, g in g_ref.items():
+        a, b = cust.grads.views[n].cpu().numpy(), g.cpu().numpy()
+        tol = 1e-5 if n == 'dec/dense/bias' else 2e-5 * np.abs(b).max() + 1e-9     # a bias in front of BatchNorm: true gradient 0
+        assert np.abs(a - b).max() <= tol, n
