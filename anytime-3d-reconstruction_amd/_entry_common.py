@@ -43,4 +43,5 @@ def parse(description, train=False):
     ap.add_argument('--missing-pr', type=float, default=0.9)
     ap.add_argument('--epochs', type=int, default=1000)
     ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--device-data', action='store_true', help='keep the split in HBM as packed bits (deviceDataLoader)')
     return ap.parse_args()

@@ -151,6 +151,33 @@ inline int grid_for(size_t total) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// Bit-packed occupancy storage: voxel v of a sample is bit (v & 7) of byte v >> 3 (numpy
+// packbits, bitorder='little').  unpack: one thread per byte -> 8 floats (two 16-byte stores), rows gathered through idx.
+__global__ void unpack_bits_gather_kernel(const unsigned char *__restrict__ packed, const int *__restrict__ idx, float *__restrict__ out,
+                                          long bytes_per_sample, long total_bytes) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_bytes; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / bytes_per_sample, k = i - b * bytes_per_sample;
+        const long src = (idx ? (long)idx[b] : b) * bytes_per_sample + k;
+        const unsigned v = packed[src];
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = (float)((v >> e) & 1u); hi[e] = (float)((v >> (4 + e)) & 1u); }
+        f32x4 *o = reinterpret_cast<f32x4 *>(out + i * 8);
+        o[0] = lo;
+        o[1] = hi;
+    }
+}
+
+__global__ void pack_bits_kernel(const float *__restrict__ x, unsigned char *__restrict__ packed, float threshold, long total_bytes) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_bytes; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 lo = reinterpret_cast<const f32x4 *>(x + i * 8)[0], hi = reinterpret_cast<const f32x4 *>(x + i * 8)[1];
+        unsigned v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v |= (lo[e] >= threshold ? 1u : 0u) << e | (hi[e] >= threshold ? 1u : 0u) << (4 + e);
+        packed[i] = (unsigned char)v;
+    }
+}
+
 }  // namespace
 
 #define VV_PACK_DISPATCH(KERNEL, TOTAL, ...)                                                                   \
@@ -245,5 +272,24 @@ VV_EXPORT int vv_shape_metrics(const float *stats, float *out4, int batch, void 
     if (!stats || !out4) return VV_ERR_NULL;
     if (batch <= 0) return VV_ERR_SHAPE;
     VV_LAUNCH(shape_metrics_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), stats, out4, batch);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_unpack_bits_gather(const void *packed, const int *index, float *out, int batch, long voxels, void *stream) {
+    if (!packed || !out) return VV_ERR_NULL;
+    if (batch <= 0 || voxels <= 0 || voxels % 8) return VV_ERR_SHAPE;
+    if (!vv_aligned16(out)) return VV_ERR_ALIGN;
+    const long bps = voxels / 8, total = bps * batch;
+    VV_LAUNCH(unpack_bits_gather_kernel, dim3(grid_for((size_t)total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+              reinterpret_cast<const unsigned char *>(packed), index, out, bps, total);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_pack_bits(const float *x, void *packed, float threshold, long n, void *stream) {
+    if (!x || !packed) return VV_ERR_NULL;
+    if (n <= 0 || n % 8) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x)) return VV_ERR_ALIGN;
+    VV_LAUNCH(pack_bits_kernel, dim3(grid_for((size_t)(n / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+              reinterpret_cast<unsigned char *>(packed), threshold, n / 8);
     return vv_launch_status();
 }

@@ -81,3 +81,58 @@ class dataLoader(object):
             'inst_list': (self._instList[dataList]).astype('float32'),
         }
         return batch_dict
+
+
+class deviceDataLoader(dataLoader):
+    """On-device variant of dataLoader: the whole split lives in HBM as packed bits (32^3 = 4 KiB per
+    sample instead of 128 KiB of float32 on the host), the epoch permutation is drawn on the device, and getNextBatch
+    gathers + unpacks the batch with one kernel -- no per-iteration host slicing or host-to-device copy
+    (reference loop: modelnet_dataset.py:74-91 + the implicit copy at test_modelnet_VAE.py:114-130).
+
+    Same attributes and batch-dict keys as dataLoader; the values are float32 CUDA tensors (what the model classes take
+    without a copy), plus 'index_list' (int32, the rows served)."""
+
+    def __init__(self, data_path, trainortest='train', partial_num=30, synthetic_size=None, voxel=None, classes=40,
+                 device='cuda:0', seed=None):
+        import ctypes
+        import torch
+        from voxvae import lib as _L
+        self._torch, self._L, self._ctypes = torch, _L, ctypes
+        self._device = torch.device(device)
+        self._gen = torch.Generator(device=self._device)
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+        super().__init__(data_path, trainortest, partial_num, synthetic_size, voxel, classes)
+
+    def _loadData(self):
+        super()._loadData()
+        torch = self._torch
+        vox = np.asarray(self._vox3DData)
+        n = vox.shape[0]
+        self._sample_shape = tuple(vox.shape[1:])
+        self._voxels = int(np.prod(self._sample_shape))
+        if self._voxels % 8:
+            raise ValueError('voxel count per sample must be a multiple of 8')
+        bits = np.packbits(vox.reshape(n, -1) > 0.5, axis=1, bitorder='little')          # binarised as the reference does (:25)
+        self._packed = torch.from_numpy(np.ascontiguousarray(bits)).to(self._device)
+        self._classes_dev = torch.from_numpy(np.asarray(self._classList, dtype=np.float32)).to(self._device)
+        self._inst_dev = torch.from_numpy(np.asarray(self._instList, dtype=np.float32)).to(self._device)
+        self._vox3DData = None                                                            # the float grids are not kept
+
+    def _dataIdxShuffle(self):
+        self._perm = self._torch.randperm(self.dataLength, device=self._device, generator=self._gen, dtype=self._torch.int32)
+        self.batchStart = 0
+
+    def getNextBatch(self, batchSize=32):
+        torch, L = self._torch, self._L
+        if self.batchStart + batchSize > self.dataLength:
+            self.epoch += 1
+            self._dataIdxShuffle()
+        idx = self._perm[self.batchStart:self.batchStart + batchSize].contiguous()
+        self.batchStart += batchSize
+        B = idx.numel()
+        out = torch.empty((B,) + self._sample_shape, dtype=torch.float32, device=self._device)
+        st = self._ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+        L.call('vv_unpack_bits_gather', L.ptr(self._packed), L.ptr(idx), L.ptr(out), B, self._voxels, st)
+        li = idx.long()
+        return {'input_images': out, 'class_list': self._classes_dev[li], 'inst_list': self._inst_dev[li], 'index_list': idx}

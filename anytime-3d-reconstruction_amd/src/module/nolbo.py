@@ -338,7 +338,8 @@ class nolboSingleObject_VAE(_ModelnetBase):
             rate, keep = _dropout if _dropout is not None else (float(np.random.rand()), None)
             keep = (torch.rand(B, Lz, device=self._device) >= rate).float() if keep is None else self._dev(keep)
             drop_mask, drop_scale = keep, 1.0 / (1.0 - rate)
-        kl, stats, metrics, de = self._trainer2d.step_from_latent(enc_out.detach().contiguous(), y, eps, drop_mask, drop_scale)
+        kl, stats, metrics, de = self._trainer2d.step_from_latent(enc_out.detach().contiguous(), y, eps, drop_mask, drop_scale,
+                                                                   l2=ae3D.L2_REG)      # + decoder.losses, nolbo.py:819-823
         if trainable_2d:
             self._opt2d.zero_grad(set_to_none=True)
             reg = [l for m in (self._encoder_head, self._encoder_backbone) if hasattr(m, 'losses') for l in m.losses]

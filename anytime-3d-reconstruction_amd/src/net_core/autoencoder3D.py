@@ -40,6 +40,13 @@ decoder_structure = {
 _WEIGHT_SUFFIX = '.voxvae.npz'
 
 
+L2_REG = 0.0005      # kernel_regularizer / bias_regularizer of every layer in the reference's autoencoder3D.py
+
+
+def _regularised(name):
+    return name.endswith('/kernel') or name == 'dense/bias'
+
+
 class Variable(object):
     """A trainable tensor with a Keras-style name (what .trainable_variables lists)."""
 
@@ -102,9 +109,65 @@ class Model(object):
 
     @property
     def losses(self):
-        """Keras collects the kernel/bias L2 regularisers (l=0.0005, autoencoder3D.py:29) here.  The modelnet
-        classes of the hot path never add them to their loss (nolbo.py:1436); only AE3D.py:82 (out of scope) does."""
-        return []
+        """Keras `model.losses`: the l2(0.0005) terms of every kernel and of the Dense bias (autoencoder3D.py:29,44,60-61,
+        88,131), one scalar per regularised variable.  The modelnet classes of the hot path never add them to their loss
+        (nolbo.py:1436); the image -> 3D model does (nolbo.py:819-823) and AE3D.py:82 (out of scope) does."""
+        p = self._engine.params
+        return [L2_REG * (p[k].float() ** 2).sum() for k in self._engine.param_shapes() if _regularised(k)]
+
+    # -- interop with checkpoints written by the reference (tf.keras variable naming)
+    def keras_variable_names(self, counters=None):
+        """[(keras name, own name)] in creation order, with Keras' default layer names: `conv3d`, `conv3d_1`, ...,
+        `batch_normalization_k`, `conv3d_transpose_k`, `dense_k` -- the per-type counters are global to the process, so
+        pass the dict returned for the previously built model (encoder first, as nolbo.py:1404-1409 builds them)."""
+        counters = dict(counters or {})
+        out = []
+        layer_of = {}
+        for k in self._engine.param_shapes():
+            layer, leaf = k.rsplit('/', 1)
+            if layer not in layer_of:
+                kind = ('batch_normalization' if layer.startswith('bn') else 'dense' if layer.startswith('dense')
+                        else 'conv3d_transpose' if layer.startswith('convT') else 'conv3d')
+                n = counters.get(kind, 0)
+                counters[kind] = n + 1
+                layer_of[layer] = kind if n == 0 else '%s_%d' % (kind, n)
+            out.append(('%s/%s:0' % (layer_of[layer], leaf), k))
+        return out, counters
+
+    def export_keras_variables(self, counters=None):
+        """{keras variable name: float32 array} in Keras layouts -- what `{v.name: v.numpy() for v in model.variables}`
+        gives on the reference side."""
+        names, counters = self.keras_variable_names(counters)
+        p = self._engine.get_params()
+        return {kn: p[own] for kn, own in names}, counters
+
+    def load_keras_variables(self, named):
+        """Inverse of export_keras_variables for dicts / npz files produced on a TensorFlow box.  Layers are matched per
+        type in creation order (numeric suffix), so the absolute counter values of the exporting process do not matter."""
+        if isinstance(named, str):
+            with np.load(named) as z:
+                named = {k: z[k] for k in z.files}
+        def split(name):
+            layer, leaf = name.split(':')[0].rsplit('/', 1)
+            layer = layer.split('/')[-1]
+            kind, _, num = layer.rpartition('_')
+            if not num.isdigit():
+                kind, num = layer, '0'
+            return kind, int(num), leaf
+        by_kind = {}
+        for name, arr in named.items():
+            kind, num, leaf = split(name)
+            by_kind.setdefault(kind, {}).setdefault(num, {})[leaf] = np.asarray(arr, dtype=np.float32)
+        own, _ = self.keras_variable_names()
+        seq = {k: [v[n] for n in sorted(v)] for k, v in by_kind.items()}
+        params, taken = {}, {}
+        for kn, name in own:
+            kind, num, leaf = split(kn)
+            layers = seq.get(kind, [])
+            if num >= len(layers) or leaf not in layers[num]:
+                raise ValueError('checkpoint lacks %s (layer %d of type %s)' % (leaf, num, kind))
+            params[name] = layers[num][leaf]
+        self._engine.set_params(params)
 
     def set_weights_dict(self, params):
         self._engine.set_params(params)

@@ -9,7 +9,7 @@ import numpy as np
 
 import _entry_common as C
 import voxvae
-from src.dataset_loader.modelnet_dataset import dataLoader
+from src.dataset_loader.modelnet_dataset import dataLoader, deviceDataLoader
 
 
 def train(
@@ -18,13 +18,14 @@ def train(
         config=None, dataset_path=None,
         save_path=None, load_path=None,
         missing_pr=0.3,
-        learn='train', batch_size=72, max_iter=None, model_class='VAE',
+        learn='train', batch_size=72, max_iter=None, model_class='VAE', device_data=False,
 ):
     import src.module.nolbo as nolbo
     cls = nolbo.nolboSingleObject_modelnet_category_VAE if model_class == 'VAE' else nolbo.nolboSingleObject_modelnet_category_AE
     model = cls(nolbo_structure=config, learning_rate=learning_rate)
     voxel = config['encoder']['input_shape'][0]
-    data_loader_test = dataLoader(data_path=dataset_path, trainortest='test', voxel=voxel)
+    # device_data: the split stays in HBM as packed bits and batches are gathered + unpacked on the GPU (no per-iteration copy)
+    data_loader_test = (deviceDataLoader if device_data else dataLoader)(data_path=dataset_path, trainortest='test', voxel=voxel)
 
     category_vectors = None
     if load_path != None:
@@ -98,5 +99,5 @@ if __name__ == '__main__':
     voxvae.set_default_dtype(a.dtype)
     sys.exit(0 if train(
         learning_rate=a.lr, config=C.make_config(a.latent, a.voxel, True), dataset_path=a.dataset_path,
-        load_path=a.load_path, missing_pr=a.missing_pr, batch_size=a.batch, max_iter=a.max_iter,
+        load_path=a.load_path, missing_pr=a.missing_pr, batch_size=a.batch, max_iter=a.max_iter, device_data=a.device_data,
     ) is not None else 1)

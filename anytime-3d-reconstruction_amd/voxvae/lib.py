@@ -52,6 +52,8 @@ SIGNATURES = {
     'vv_binary_loss': (_i, [_vp, _vp, _f, _f, _f, _vp, _i, ctypes.c_long, _vp]),
     'vv_voxel_precision_recall': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _i, ctypes.c_long, _vp]),
     'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'vv_unpack_bits_gather': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
+    'vv_pack_bits': (_i, [_vp, _vp, _f, _l, _vp]),
     'vv_regulizer_loss': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'vv_bn_workspace_bytes': (_sz, [_l, _i]),

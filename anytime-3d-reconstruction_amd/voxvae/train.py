@@ -144,14 +144,19 @@ class Trainer:
         self._apply()
         return kl, stats, metrics
 
-    def step_from_latent(self, enc_out, y, eps=None, drop_mask=None, drop_scale=1.0):
+    def step_from_latent(self, enc_out, y, eps=None, drop_mask=None, drop_scale=1.0, l2=0.0):
         """Decoder-only step for the image -> 3D model (nolbo.py:786-833): enc_out [B, 2L] (mean | logVar) comes from a 2D
         encoder owned by the caller.  Trains the decoder and returns (loss_kl, stats, metrics, d total / d enc_out) so the
-        caller can continue the backward pass through its own encoder."""
+        caller can continue the backward pass through its own encoder.  l2: coefficient of the decoder's kernel / bias
+        regularisers when the caller's loss includes them."""
         self.dec.ensure_packed()
         B = enc_out.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         kl, stats, metrics, de = self._latent_decoder(enc_out, y, eps, drop_mask, drop_scale, B, inv_gb)
+        if l2 > 0:      # + sum(decoder.losses) in the total loss (nolbo.py:819-823): d/dw of l2 * sum(w^2)
+            for name, _ in self.order:
+                if name.endswith('/kernel') or name == 'dec/dense/bias':
+                    self._g(name).add_(self._p(name), alpha=2.0 * l2 / self.world)
         self._apply()
         return kl, stats, metrics, de
 

@@ -225,6 +225,13 @@ int vv_reparam_kl_bwd(const float *enc_out, const float *eps, const float *dz, c
 int vv_adam_step(float *param, const float *grad, float *m, float *v, long n, float lr_t, float beta1, float beta2,
                  float epsilon, void *stream);
 
+/* ---- bit-packed occupancy grids (modelnet_dataset.py:74-91 keeps float32 grids on the host and copies a batch per
+ * iteration; 32^3 voxels are 4 KiB as bits).  Voxel v of a sample is bit (v & 7) of byte v >> 3.
+ * vv_unpack_bits_gather: out[b][v] = bit v of sample index[b] (index NULL: b) as 0.0f / 1.0f; voxels % 8 == 0.
+ * vv_pack_bits: bit = x >= threshold, over n floats (n % 8 == 0). */
+int vv_unpack_bits_gather(const void *packed, const int *index, float *out, int batch, long voxels, void *stream);
+int vv_pack_bits(const float *x, void *packed, float threshold, long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,6 +168,8 @@ def test_entry_scripts_run_on_synthetic_data(tmp_path):
     assert cv.shape == (40, 64) and os.path.exists(tmp_path / 'category_vectors.npy')
     l8 = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2)
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
+    l8d = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2, device_data=True)
+    assert l8d.shape == (8,) and np.all(np.isfinite(l8d))
     # latent-dropout training (the _dr scripts) and the (D*D, D) text dumps of test_modelnet_3D.py
     res = tr.train(training_epoch=1, learning_rate=1e-3, batch_size=4, config=cfg, dataset_path='synthetic:16:16', max_iter=2, dropout=True)
     assert np.all(np.isfinite(res[0]))
@@ -317,3 +319,85 @@ def test_class_conditional_prior_model(tmp_path):
     assert all(np.all(np.isfinite(r)) for r in res)
     l8 = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2)
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
+
+
+def test_bit_packed_device_data_path():
+    """pack/unpack kernels are exact inverses of numpy packbits(bitorder='little'), and the
+    device-resident loader serves the same rows as the host loader's arrays, as CUDA tensors the models take directly."""
+    sys.path.insert(0, PKG)
+    import ctypes
+    import voxvae
+    from voxvae import lib as L
+    from voxvae import synthetic as syn
+    from src.dataset_loader.modelnet_dataset import dataLoader, deviceDataLoader
+    voxvae.set_default_dtype('bf16')
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(0)
+    x = (rng.random((5, 16, 16, 16, 1)) < 0.3).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    packed = torch.empty(5 * 4096 // 8, dtype=torch.uint8, device='cuda:0')
+    L.call('vv_pack_bits', L.ptr(xd), L.ptr(packed), 0.5, xd.numel(), st)
+    np.testing.assert_array_equal(packed.cpu().numpy(), np.packbits(x.reshape(-1) > 0.5, bitorder='little'))
+    idx = torch.tensor([3, 0, 4], dtype=torch.int32, device='cuda:0')
+    out = torch.empty(3, 16, 16, 16, 1, dtype=torch.float32, device='cuda:0')
+    L.call('vv_unpack_bits_gather', L.ptr(packed), L.ptr(idx), L.ptr(out), 3, 4096, st)
+    np.testing.assert_array_equal(out.cpu().numpy(), x[[3, 0, 4]])
+    assert L.load().vv_unpack_bits_gather(L.ptr(packed), None, L.ptr(out), 3, 4097, st) == -2
+
+    host = dataLoader('synthetic:20:32', trainortest='test')
+    dev = deviceDataLoader('synthetic:20:32', trainortest='test', seed=1)
+    assert dev.dataLength == host.dataLength == 20 and dev._packed.shape == (20, 4096) and dev._packed.dtype == torch.uint8
+    seen = []
+    for _ in range(3):
+        b = dev.getNextBatch(batchSize=8)
+        rows = b['index_list'].cpu().numpy()
+        seen.append(rows)
+        assert b['input_images'].is_cuda and b['input_images'].shape == (8, 32, 32, 32, 1)
+        np.testing.assert_array_equal(b['input_images'].cpu().numpy(), host._vox3DData[rows])
+        np.testing.assert_array_equal(b['class_list'].cpu().numpy(), host._classList[rows])
+    assert dev.epoch == 1 and len(set(seen[0]) | set(seen[1])) == 16          # a permutation inside an epoch
+    import src.module.nolbo as nolbo
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=syn.make_config(32, 64, True))
+    b = dev.getNextBatch(batchSize=8)
+    out = m.getEval(inputs=(b['input_images'], b['input_images'], b['class_list']), category_vectors=syn.make_category_vectors(40, 64))
+    assert np.array(out[0]).shape == (8, 32, 32, 32, 1) and np.isfinite(float(out[1]))
+
+
+def test_keras_named_checkpoint_interop_and_losses():
+    """variables under tf.keras' default names (`conv3d_1/kernel:0`, `batch_normalization_4/gamma:0`,
+    `conv3d_transpose/kernel:0`, `dense/bias:0`) round-trip between two models even when the exporting process had other
+    layer counters; `.losses` carries the l2(0.0005) terms of the reference's layers."""
+    sys.path.insert(0, PKG)
+    import voxvae
+    voxvae.set_default_dtype('f32')
+    import src.net_core.autoencoder3D as ae3D
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(32, 64, True)
+    enc, dec = ae3D.encoder3D(cfg['encoder']), ae3D.decoder3D(cfg['decoder'])
+    enc.set_weights_dict(syn.make_encoder_params(cfg['encoder']))
+    dec.set_weights_dict(syn.make_decoder_params(cfg['decoder']))
+    ev, counters = enc.export_keras_variables()
+    dv, counters = dec.export_keras_variables(counters)
+    assert 'conv3d/kernel:0' in ev and 'conv3d_4/kernel:0' in ev and 'batch_normalization_3/moving_variance:0' in ev
+    assert 'dense/kernel:0' in dv and 'dense/bias:0' in dv and 'batch_normalization_4/gamma:0' in dv
+    assert 'conv3d_transpose/kernel:0' in dv and 'conv3d_transpose_4/kernel:0' in dv and counters['batch_normalization'] == 9
+    assert ev['conv3d_1/kernel:0'].shape == (4, 4, 4, 64, 128) and dv['conv3d_transpose_1/kernel:0'].shape == (4, 4, 4, 256, 512)
+    # a process that had built other models first: every suffix shifted, prefixed with a scope
+    shifted = {}
+    for k, v in dv.items():
+        layer, leaf = k.split('/')
+        kind, _, num = layer.rpartition('_')
+        if not num.isdigit():
+            kind, num = layer, '0'
+        shifted['decoder/%s_%d/%s' % (kind, int(num) + 7, leaf)] = v
+    dec2 = ae3D.decoder3D(cfg['decoder'], seed=5)
+    dec2.load_keras_variables(shifted)
+    for k, v in dec.get_weights_dict().items():
+        np.testing.assert_array_equal(dec2.get_weights_dict()[k], v)
+    with pytest.raises(ValueError):
+        dec2.load_keras_variables({k: v for k, v in dv.items() if 'dense/bias' not in k})
+    reg = dec.losses
+    p = dec.get_weights_dict()
+    assert len(reg) == 7                                                   # dense kernel + bias, 5 transposed-conv kernels
+    np.testing.assert_allclose(sum(float(r) for r in reg), 0.0005 * sum(float((p[k].astype(np.float64) ** 2).sum()) for k in p
+                               if k.endswith('/kernel') or k == 'dense/bias'), rtol=1e-5)
