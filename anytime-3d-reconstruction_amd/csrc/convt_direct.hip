@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
     constexpr int SPR = RB / 16;         // 16-byte slots per row (16 for CIN = 128)
     constexpr int KS = CIN / 16;         // MFMA k-steps per tap
     constexpr int NT = COUT / 32;        // channel tiles
-    constexpr int HALF = MT == 4 ? KS / 2 : 2;   // k-steps per weight prefetch group (register budget: 2 waves/SIMD at MT 2)
+    constexpr int HALF = 2;              // k-steps per weight prefetch group (4 groups in the ring = 64 VGPRs)
     constexpr int GPT = KS / HALF;       // groups per tap
     constexpr int GPP = 8 * GPT;         // groups per parity
     constexpr int SPITCH = COUT * 2 + 16;

@@ -178,6 +178,11 @@ __global__ void pack_bits_kernel(const float *__restrict__ x, unsigned char *__r
     }
 }
 
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS *__restrict__ src, TD *__restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = static_cast<TD>((float)src[i]);
+}
+
 }  // namespace
 
 #define VV_PACK_DISPATCH(KERNEL, TOTAL, ...)                                                                   \
@@ -291,5 +296,22 @@ VV_EXPORT int vv_pack_bits(const float *x, void *packed, float threshold, long n
     if (!vv_aligned16(x)) return VV_ERR_ALIGN;
     VV_LAUNCH(pack_bits_kernel, dim3(grid_for((size_t)(n / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
               reinterpret_cast<unsigned char *>(packed), threshold, n / 8);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_convert(const void *src, void *dst, long n, int src_dtype, int dst_dtype, void *stream) {
+    if (!src || !dst) return VV_ERR_NULL;
+    if ((src_dtype != VV_F32 && src_dtype != VV_BF16) || (dst_dtype != VV_F32 && dst_dtype != VV_BF16)) return VV_ERR_DTYPE;
+    if (n <= 0) return VV_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 g(grid_for((size_t)n)), b(256);
+    if (src_dtype == VV_F32 && dst_dtype == VV_BF16)
+        VV_LAUNCH((convert_kernel<float, __bf16>), g, b, 0, st, reinterpret_cast<const float *>(src), reinterpret_cast<__bf16 *>(dst), n);
+    else if (src_dtype == VV_BF16 && dst_dtype == VV_F32)
+        VV_LAUNCH((convert_kernel<__bf16, float>), g, b, 0, st, reinterpret_cast<const __bf16 *>(src), reinterpret_cast<float *>(dst), n);
+    else if (src_dtype == VV_F32)
+        VV_LAUNCH((convert_kernel<float, float>), g, b, 0, st, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(dst), n);
+    else
+        VV_LAUNCH((convert_kernel<__bf16, __bf16>), g, b, 0, st, reinterpret_cast<const __bf16 *>(src), reinterpret_cast<__bf16 *>(dst), n);
     return vv_launch_status();
 }

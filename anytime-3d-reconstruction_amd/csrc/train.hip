@@ -9,8 +9,34 @@ namespace {
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // Column reductions over x[R][C] (C % 4 == 0, C <= 1024): workgroup = a slab of rows, lane = 4 channels.
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): du = dy * act'(u), u = x*scale + shift; sum du, sum du * xhat.
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+// 4 consecutive elements of a float32 or bf16 tensor as float4 (element index 4*i4 .. +3), and the store back.
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T *p, long i4) {
+    if constexpr (sizeof(T) == 4) {
+        return reinterpret_cast<const f32x4 *>(p)[i4];
+    } else {
+        const bf16x4 v = reinterpret_cast<const bf16x4 *>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T *p, long i4, f32x4 v) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4 *>(p)[i4] = v;
+    } else {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
+        reinterpret_cast<bf16x4 *>(p)[i4] = o;
+    }
+}
+// runtime-typed variant for the weight-gradient staging (dtype flag in the argument block)
+__device__ __forceinline__ f32x4 ld4_rt(const void *p, long elem, int is_bf16) {
+    return is_bf16 ? ld4(reinterpret_cast<const __bf16 *>(p) + elem, 0) : ld4(reinterpret_cast<const float *>(p) + elem, 0);
+}
+
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
                                                         float *__restrict__ partial, long R, int C, int rows_per_block, int act) {
@@ -31,12 +57,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
     }
     if (rsub < rows_par) {
         for (long r = r0 + rsub; r < r1; r += rows_par) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + r * C + c4 * 4);
+            const f32x4 v = ld4(x + r * C, c4);
             if (MODE == 0) {
                 s0 += v;
                 s1 += v * v;
             } else {
-                const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * C + c4 * 4);
+                const f32x4 g = ld4(dy + r * C, c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float u = v[e] * sc[e] + sh[e];
@@ -63,14 +89,29 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
     }
 }
 
+// Sum of the per-block partials of 16 channels in double, by 256 threads = 16 channels x 16 slices of the block list;
+// the 16 slice sums of a channel are added in slice order (deterministic).  Result valid in threads 0..15 (channel = tid).
+__device__ __forceinline__ void bn_partial_sums(const float *__restrict__ partial, int nblk, int C, int c0, double &s, double &ss) {
+    __shared__ double red[2][16][17];
+    const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4, c = c0 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int k = sl; k < nblk; k += 16) { a += partial[((size_t)k * 2) * C + c]; b += partial[((size_t)k * 2 + 1) * C + c]; }
+    red[0][sl][cl] = a; red[1][sl][cl] = b;
+    __syncthreads();
+    s = 0.0; ss = 0.0;
+    if (tid < 16)
+        for (int k = 0; k < 16; ++k) { s += red[0][k][tid]; ss += red[1][k][tid]; }
+}
+
 // Forward finalise: batch mean / biased variance -> scale, shift, rstd; moving statistics update (momentum).
-__global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblk, long R, int C, const float *gamma,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float *__restrict__ partial, int nblk, long R, int C, const float *gamma,
                                          const float *beta, float eps, float momentum, float *mean, float *var, float *rstd,
                                          float *scale, float *shift, float *moving_mean, float *moving_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    double s, ss;
+    bn_partial_sums(partial, nblk, C, blockIdx.x * 16, s, ss);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
     const double m = s / (double)R;
     double v = ss / (double)R - m * m;
     if (v < 0.0) v = 0.0;
@@ -83,37 +124,39 @@ __global__ void bn_stats_finalize_kernel(const float *__restrict__ partial, int 
 }
 
 // Backward finalise: dbeta = sum du, dgamma = sum du*xhat
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *dgamma, float *dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((size_t)b * 2) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *dgamma, float *dbeta) {
+    double s, ss;
+    bn_partial_sums(partial, nblk, C, blockIdx.x * 16, s, ss);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
 }
 
 // y = act(x*scale + shift)
-__global__ void bn_act_fwd_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
-                                  float *__restrict__ y, long n4, int C, int act) {
+template <typename T>
+__global__ void bn_act_fwd_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                  T *__restrict__ y, long n4, int C, int act) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 v = ld4(x, i);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = vv_apply_act(v[e] * sc[e] + sh[e], act);
-        reinterpret_cast<f32x4 *>(y)[i] = o;
+        st4(y, i, o);
     }
 }
 
 // dx = gamma*rstd * (du - dbeta/R - xhat*dgamma/R),  du = dy*act'(x*scale+shift)
-__global__ void bn_act_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ scale,
+template <typename T>
+__global__ void bn_act_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ scale,
                                   const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
-                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, float *__restrict__ dx,
+                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, T *__restrict__ dx,
                                   long n4, int C, float invR, int act) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
-        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i], g = reinterpret_cast<const f32x4 *>(dy)[i];
+        const f32x4 v = ld4(x, i), g = ld4(dy, i);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -125,7 +168,7 @@ __global__ void bn_act_bwd_kernel(const float *__restrict__ x, const float *__re
             const float xh = (v[e] - mean[c + e]) * rstd[c + e];
             o[e] = scale[c + e] * (d - dbeta[c + e] * invR - xh * dgamma[c + e] * invR);
         }
-        reinterpret_cast<f32x4 *>(dx)[i] = o;
+        st4(dx, i, o);
     }
 }
 
@@ -141,14 +184,15 @@ __global__ void bn_act_bwd_kernel(const float *__restrict__ x, const float *__re
 // wants lane = m, k = row: rows of the chunk ARE k, no transposition needed).  grid.y splits the reduction; slabs are
 // summed in split order by wgrad_reduce_kernel (deterministic).
 struct WgradArgs {
-    const float *A;
-    const float *G;
+    const void *A;      // float32 or bf16 (a_bf16)
+    const void *G;      // float32 or bf16 (g_bf16)
     float *slabs;       // [splits][M][N]
     long R;             // reduction rows
     int M, N;
     int lda;            // AMODE 0 row pitch (elements)
     int din_log2, cin;  // AMODE 1/2: source grid side (log2) and channels
     int rows_per_split;
+    int a_bf16, g_bf16;
 };
 
 template <int AMODE, int BN>
@@ -182,7 +226,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             if (r < r_end) {
                 if (AMODE == 0) {
                     const int m = m0 + c4 * 4;
-                    if (m < a.M) v = *reinterpret_cast<const f32x4 *>(a.A + r * a.lda + m);
+                    if (m < a.M) v = ld4_rt(a.A, r * a.lda + m, a.a_bf16);
                 } else {
                     const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
                     const long b = r >> (3 * lo);
@@ -190,14 +234,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
                         const int m = m0 + c4 * 4, t = m / a.cin, ci = m % a.cin;   // cin % 64 == 0: a tile stays inside one tap
                         const int id = 2 * od - 1 + (t >> 4), ih = 2 * oh - 1 + ((t >> 2) & 3), iw = 2 * ow - 1 + (t & 3);
                         if (m < a.M && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
-                            v = *reinterpret_cast<const f32x4 *>(a.A + ((((b << li) + id << li) + ih << li) + iw) * a.cin + ci);
+                            v = ld4_rt(a.A, ((((b << li) + id << li) + ih << li) + iw) * a.cin + ci, a.a_bf16);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int t = c4 * 4 + e;
                             const int id = 2 * od - 1 + (t >> 4), ih = 2 * oh - 1 + ((t >> 2) & 3), iw = 2 * ow - 1 + (t & 3);
                             if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
-                                v[e] = a.A[(((b << li) + id << li) + ih << li) + iw];
+                                v[e] = reinterpret_cast<const float *>(a.A)[(((b << li) + id << li) + ih << li) + iw];   // cin = 1 sources are float32 grids
                         }
                     }
                 }
@@ -210,7 +254,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const long r = rc + rr;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int nn = n0 + c4 * 4;
-            if (r < r_end && nn < a.N) v = *reinterpret_cast<const f32x4 *>(a.G + r * a.N + nn);
+            if (r < r_end && nn < a.N) v = ld4_rt(a.G, r * a.N + nn, a.g_bf16);
             *reinterpret_cast<f32x4 *>(&Gs[rr][c4 * 4]) = v;
         }
         __syncthreads();
@@ -356,12 +400,13 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
-__global__ void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long R, int C) {
+template <typename T>
+__global__ void colsum_kernel(const T *__restrict__ x, float *__restrict__ out, long R, int C) {
     // out[c] = sum_r x[r][c] (Dense bias gradient; R = batch, small)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (long r = 0; r < R; ++r) s += x[r * C + c];
+    for (long r = 0; r < R; ++r) s += (float)x[r * C + c];
     out[c] = s;
 }
 
@@ -379,46 +424,69 @@ inline int bn_blocks(long R) {
 
 VV_EXPORT size_t vv_bn_workspace_bytes(long rows, int channels) { return (size_t)bn_blocks(rows) * 2 * channels * sizeof(float); }
 
-VV_EXPORT int vv_bn_train_stats(const float *x, long rows, int channels, const float *gamma, const float *beta, float eps,
+VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const float *gamma, const float *beta, float eps,
                                 float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
-                                float *moving_mean, float *moving_var, void *workspace, size_t workspace_bytes, void *stream) {
+                                float *moving_mean, float *moving_var, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !gamma || !beta || !mean || !var || !rstd || !scale || !shift) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = bn_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
-    VV_LAUNCH((bn_reduce_kernel<0>), dim3(nb), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, part, rows, channels, rpb, 0);
-    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nb, rows, channels, gamma, beta, eps,
+    if (dtype == VV_BF16)
+        VV_LAUNCH((bn_reduce_kernel<0, __bf16>), dim3(nb), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), nullptr, nullptr, nullptr,
+                  nullptr, nullptr, part, rows, channels, rpb, 0);
+    else
+        VV_LAUNCH((bn_reduce_kernel<0, float>), dim3(nb), dim3(256), 0, st, reinterpret_cast<const float *>(x), nullptr, nullptr, nullptr,
+                  nullptr, nullptr, part, rows, channels, rpb, 0);
+    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, rows, channels, gamma, beta, eps,
               momentum, mean, var, rstd, scale, shift, moving_mean, moving_var);
     return vv_launch_status();
 }
 
-VV_EXPORT int vv_bn_act_fwd(const float *x, const float *scale, const float *shift, float *y, long rows, int channels, int act,
-                            void *stream) {
+VV_EXPORT int vv_bn_act_fwd(const void *x, const float *scale, const float *shift, void *y, long rows, int channels, int act,
+                            int dtype, void *stream) {
     if (!x || !scale || !shift || !y) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (rows <= 0 || channels <= 0 || channels % 4) return VV_ERR_SHAPE;
     const long n4 = rows * channels / 4;
-    VV_LAUNCH(bn_act_fwd_kernel, dim3(grid_1d(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, scale, shift, y, n4, channels, act);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == VV_BF16)
+        VV_LAUNCH(bn_act_fwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), scale, shift,
+                  reinterpret_cast<__bf16 *>(y), n4, channels, act);
+    else
+        VV_LAUNCH(bn_act_fwd_kernel<float>, dim3(grid_1d(n4)), dim3(256), 0, st, reinterpret_cast<const float *>(x), scale, shift,
+                  reinterpret_cast<float *>(y), n4, channels, act);
     return vv_launch_status();
 }
 
-VV_EXPORT int vv_bn_act_bwd(const float *x, const float *dy, const float *scale, const float *shift, const float *mean,
-                            const float *rstd, float *dgamma, float *dbeta, float *dx, long rows, int channels, int act,
-                            void *workspace, size_t workspace_bytes, void *stream) {
+VV_EXPORT int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, const float *shift, const float *mean,
+                            const float *rstd, float *dgamma, float *dbeta, void *dx, long rows, int channels, int act,
+                            int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !dy || !scale || !shift || !mean || !rstd || !dgamma || !dbeta || !dx) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = bn_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
-    VV_LAUNCH((bn_reduce_kernel<1>), dim3(nb), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, part, rows, channels, rpb, act);
-    VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
     const long n4 = rows * channels / 4;
-    VV_LAUNCH(bn_act_bwd_kernel, dim3(grid_1d(n4)), dim3(256), 0, st, x, dy, scale, shift, mean, rstd, dgamma, dbeta, dx, n4, channels,
-              1.0f / (float)rows, act);
+    if (dtype == VV_BF16) {
+        const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *dyb = reinterpret_cast<const __bf16 *>(dy);
+        VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
+        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
+        VV_LAUNCH(bn_act_bwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, dgamma, dbeta,
+                  reinterpret_cast<__bf16 *>(dx), n4, channels, 1.0f / (float)rows, act);
+    } else {
+        const float *xf = reinterpret_cast<const float *>(x), *dyf = reinterpret_cast<const float *>(dy);
+        VV_LAUNCH((bn_reduce_kernel<1, float>), dim3(nb), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, part, rows, channels, rpb, act);
+        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
+        VV_LAUNCH(bn_act_bwd_kernel<float>, dim3(grid_1d(n4)), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, dgamma, dbeta,
+                  reinterpret_cast<float *>(dx), n4, channels, 1.0f / (float)rows, act);
+    }
     return vv_launch_status();
 }
 
@@ -450,26 +518,30 @@ int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha
 
 VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) { return wgrad_plan(rows, m, n).ws; }
 
-VV_EXPORT int vv_wgrad_dense(const float *a, const float *g, float *dw, long rows, int m, int n, int lda, void *workspace,
-                             size_t workspace_bytes, void *stream) {
+VV_EXPORT int vv_wgrad_dense(const void *a, const void *g, float *dw, long rows, int m, int n, int lda, int a_dtype, int g_dtype,
+                             void *workspace, size_t workspace_bytes, void *stream) {
     if (!a || !g || !dw) return VV_ERR_NULL;
+    if ((a_dtype != VV_F32 && a_dtype != VV_BF16) || (g_dtype != VV_F32 && g_dtype != VV_BF16)) return VV_ERR_DTYPE;
     if (rows <= 0 || m <= 0 || n <= 0 || m % 4 || n % 4 || lda % 4) return VV_ERR_SHAPE;
     const WgradPlan p = wgrad_plan(rows, m, n);
     if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
-    WgradArgs w{a, g, reinterpret_cast<float *>(workspace), rows, m, n, lda, 0, 0, p.rps};
+    WgradArgs w{a, g, reinterpret_cast<float *>(workspace), rows, m, n, lda, 0, 0, p.rps, a_dtype == VV_BF16, g_dtype == VV_BF16};
     return launch_wgrad<0>(w, p, dw, 1.f, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
-VV_EXPORT int vv_wgrad_conv_k4s2(const float *src, const float *g, float *dw, int batch, int side, int cin, int cout,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int batch, int side, int cin, int cout, int src_dtype,
+                                 int g_dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!src || !g || !dw) return VV_ERR_NULL;
+    if ((src_dtype != VV_F32 && src_dtype != VV_BF16) || (g_dtype != VV_F32 && g_dtype != VV_BF16)) return VV_ERR_DTYPE;
+    if (cin == 1 && src_dtype != VV_F32) return VV_ERR_DTYPE;               // single-channel sources are float32 grids
     if (batch <= 0 || side < 2 || !vv_is_pow2(side) || cout % 4 || (cin != 1 && cin % 64)) return VV_ERR_SHAPE;
     const int o = side / 2;
     const long rows = (long)batch * o * o * o;
     const int m = 64 * cin;
     const WgradPlan p = wgrad_plan(rows, m, cout);
     if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
-    WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps};
+    WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps, src_dtype == VV_BF16,
+                g_dtype == VV_BF16};
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return cin == 1 ? launch_wgrad<2>(w, p, dw, 1.f, 0, st) : launch_wgrad<1>(w, p, dw, 1.f, 0, st);
 }
@@ -523,9 +595,12 @@ VV_EXPORT int vv_adam_step(float *param, const float *grad, float *m, float *v, 
     return vv_launch_status();
 }
 
-VV_EXPORT int vv_colsum(const float *x, float *out, long rows, int cols, void *stream) {
+VV_EXPORT int vv_colsum(const void *x, float *out, long rows, int cols, int dtype, void *stream) {
     if (!x || !out) return VV_ERR_NULL;
+    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (rows <= 0 || cols <= 0) return VV_ERR_SHAPE;
-    VV_LAUNCH(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, rows, cols);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == VV_BF16) VV_LAUNCH(colsum_kernel<__bf16>, dim3((cols + 255) / 256), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), out, rows, cols);
+    else VV_LAUNCH(colsum_kernel<float>, dim3((cols + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float *>(x), out, rows, cols);
     return vv_launch_status();
 }

@@ -98,6 +98,6 @@ config = make_config(latent_dim, 64)
 
 if __name__ == '__main__':
     a = C.parse(__doc__, train=True)
-    voxvae.set_default_dtype('f32')          # fit() runs the exact-f32 path this round
+    voxvae.set_default_dtype(a.dtype)        # 'f32': exact-f32 parity mode; 'bf16': mixed precision (float32 master weights)
     sys.exit(0 if train(training_epoch=a.epochs, learning_rate=a.lr, batch_size=a.batch, config=make_config(a.latent, a.voxel),
                         dataset_path=a.dataset_path, save_path=a.save_path, load_path=a.load_path, max_iter=a.max_iter) is not None else 1)

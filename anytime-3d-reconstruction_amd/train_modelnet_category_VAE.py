@@ -109,7 +109,7 @@ config = C.make_config(latent_dim, 64, True)   # the reference literal (64^3); m
 
 if __name__ == '__main__':
     a = C.parse(__doc__, train=True)
-    voxvae.set_default_dtype('f32')            # training runs on the exact-f32 MFMA path
+    voxvae.set_default_dtype(a.dtype)        # 'f32': exact-f32 parity mode; 'bf16': mixed precision (float32 master weights)
     sys.exit(0 if train(
         training_epoch=a.epochs, learning_rate=a.lr, batch_size=a.batch,
         config=C.make_config(a.latent, a.voxel, True),

@@ -54,19 +54,20 @@ SIGNATURES = {
     'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'vv_unpack_bits_gather': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'vv_pack_bits': (_i, [_vp, _vp, _f, _l, _vp]),
+    'vv_convert': (_i, [_vp, _vp, _l, _i, _i, _vp]),
     'vv_regulizer_loss': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'vv_bn_workspace_bytes': (_sz, [_l, _i]),
-    'vv_bn_train_stats': (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'vv_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
-    'vv_bn_act_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _sz, _vp]),
+    'vv_bn_train_stats': (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'vv_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    'vv_bn_act_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
     'vv_wgrad_workspace_bytes': (_sz, [_l, _i, _i]),
-    'vv_wgrad_dense': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
-    'vv_wgrad_conv_k4s2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_wgrad_dense': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_wgrad_conv_k4s2': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_unpack_meanpool_grad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_unpack_convT_dense_grad': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_transpose_f32': (_i, [_vp, _vp, _i, _i, _vp]),
-    'vv_colsum': (_i, [_vp, _vp, _l, _i, _vp]),
+    'vv_colsum': (_i, [_vp, _vp, _l, _i, _i, _vp]),
     'vv_bce_bwd': (_i, [_vp, _vp, _vp, _i, _l, _f, _f, _f, _vp]),
     'vv_reparam_kl_bwd': (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _f, _vp]),
     'vv_adam_step': (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _vp]),

@@ -70,8 +70,13 @@ class _BN:
 
 class Trainer:
     def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None):
-        if (enc is not None and enc.dt != L.VV_F32) or dec.dt != L.VV_F32:
-            raise NotImplementedError("training runs in 'f32' (exact-f32 MFMA) this round; build the model with dtype 'f32'")
+        if enc is not None and enc.dt != dec.dt:
+            raise ValueError('encoder and decoder engines must share one activation dtype')
+        # 'f32': everything on the exact-f32 MFMA path (parity mode).  'bf16': mixed precision -- activations, their
+        # gradients and the MFMA operands in bf16, float32 master weights / Adam moments / BatchNorm statistics / losses,
+        # weight gradients accumulated in float32 (f32 MFMA over widened operands).
+        self.dt = dec.dt
+        self.tdt = torch.bfloat16 if self.dt == L.VV_BF16 else torch.float32
         self.enc, self.dec, self.var, self.lr = enc, dec, variational, float(learning_rate)   # enc None: decoder-only (image -> 3D model)
         self.dev = dec.device
         self.world, self.group = int(world_size), group
@@ -97,39 +102,93 @@ class Trainer:
     def _empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
 
+    def _aempty(self, *shape):
+        return torch.empty(shape, dtype=self.tdt, device=self.dev)        # an activation / activation gradient
+
+    @staticmethod
+    def _dt(t):
+        return L.VV_BF16 if t.dtype == torch.bfloat16 else L.VV_F32
+
+    def _cast(self, t):
+        """float32 tensor -> the activation dtype (a copy only in bf16 mode)."""
+        if self.dt == L.VV_F32:
+            return t
+        o = torch.empty(t.shape, dtype=self.tdt, device=self.dev)
+        L.call('vv_convert', L.ptr(t), L.ptr(o), t.numel(), L.VV_F32, self.dt, _st())
+        return o
+
     def _bn_fwd(self, c, rows, ch, eng, prefix, act):
         bn = _BN(ch, self.dev)
         p = eng.params
         ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, ch))
         L.call('vv_bn_train_stats', L.ptr(c), rows, ch, L.ptr(p[prefix + '/gamma']), L.ptr(p[prefix + '/beta']), BN_EPS, BN_MOMENTUM,
                L.ptr(bn.mean), L.ptr(bn.var), L.ptr(bn.rstd), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(p[prefix + '/moving_mean']),
-               L.ptr(p[prefix + '/moving_variance']), L.ptr(ws), ws.numel(), _st())
+               L.ptr(p[prefix + '/moving_variance']), self._dt(c), L.ptr(ws), ws.numel(), _st())
         h = torch.empty_like(c)
-        L.call('vv_bn_act_fwd', L.ptr(c), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(h), rows, ch, act, _st())
+        L.call('vv_bn_act_fwd', L.ptr(c), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(h), rows, ch, act, self._dt(c), _st())
         return h, bn
 
     def _bn_bwd(self, c, dh, bn, rows, gname, bname, act):
         dc = torch.empty_like(c)
         ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, bn.c))
         L.call('vv_bn_act_bwd', L.ptr(c), L.ptr(dh), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(bn.mean), L.ptr(bn.rstd),
-               L.ptr(self._g(gname)), L.ptr(self._g(bname)), L.ptr(dc), rows, bn.c, act, L.ptr(ws), ws.numel(), _st())
+               L.ptr(self._g(gname)), L.ptr(self._g(bname)), L.ptr(dc), rows, bn.c, act, self._dt(c), L.ptr(ws), ws.numel(), _st())
         return dc
 
-    def _dense(self, x, panel, m, n, k, shift=None):
-        y = self._empty(m, n)
-        ws = self.ws.get(L.load().vv_dense_workspace_bytes(m, n, k, L.VV_F32))
-        L.call('vv_dense_fwd', L.ptr(x), L.ptr(panel), None, L.ptr(shift), L.ptr(y), m, n, k, 0, L.VV_F32, L.VV_F32, L.ptr(ws),
+    def _dense(self, x, panel, m, n, k, shift=None, f32_out=False):
+        """y[m,n] = x[m,k] @ panel[n,k]^T (+ shift); x and panel in the activation dtype, y in it too unless f32_out."""
+        y = self._empty(m, n) if f32_out else self._aempty(m, n)
+        ws = self.ws.get(L.load().vv_dense_workspace_bytes(m, n, k, self.dt))
+        L.call('vv_dense_fwd', L.ptr(x), L.ptr(panel), None, L.ptr(shift), L.ptr(y), m, n, k, 0, self.dt, self._dt(y), L.ptr(ws),
                ws.numel(), _st())
         return y
 
+    def _transposed_panel(self, panel_f32, rows, cols):
+        """[rows][cols] float32 panel -> its transpose [cols][rows] in the activation dtype (vv_pack_dense reads a Keras
+        [In][Out] array and writes [Out][In])."""
+        o = self._aempty(cols, rows)
+        L.call('vv_pack_dense', L.ptr(panel_f32), L.ptr(o), rows, cols, self.dt, _st())
+        return o
+
     def _wgrad_dense(self, a, g, out, rows, m, n):
         ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(rows, m, n))
-        L.call('vv_wgrad_dense', L.ptr(a), L.ptr(g), L.ptr(out), rows, m, n, m, L.ptr(ws), ws.numel(), _st())
+        L.call('vv_wgrad_dense', L.ptr(a), L.ptr(g), L.ptr(out), rows, m, n, m, self._dt(a), self._dt(g), L.ptr(ws), ws.numel(), _st())
 
     def _wgrad_conv(self, src, g, out, batch, side, cin, cout):
         o = side // 2
         ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(batch * o ** 3, 64 * cin, cout))
-        L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), batch, side, cin, cout, L.ptr(ws), ws.numel(), _st())
+        L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), batch, side, cin, cout, self._dt(src), self._dt(g), L.ptr(ws),
+               ws.numel(), _st())
+
+    def _conv(self, x, w_keras, B, side, cin, cout):
+        """Conv3D k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cin,cout]: the forward layers and the
+        data gradients of the transposed layers."""
+        dt, st = self.dt, _st()
+        wp = self._aempty(cout, 64 * cin)
+        L.call('vv_pack_conv_k4', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
+        y = self._aempty(B, side // 2, side // 2, side // 2, cout)
+        if L.load().vv_conv3d_k4s2_direct_supported(side, cin, cout, dt):
+            L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
+        else:
+            ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, cin, cout, dt))
+            L.call('vv_conv3d_k4s2_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
+        return y
+
+    def _convT(self, x, w_keras, B, side, cin, cout):
+        """Conv3DTranspose k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cout,cin]: the forward
+        transposed layers and the data gradients of the strided convolutions."""
+        dt, st = self.dt, _st()
+        y = self._aempty(B, 2 * side, 2 * side, 2 * side, cout)
+        if L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt):
+            wf = self._aempty(64 * cin * cout)
+            L.call('vv_pack_convT_k4s2_frag', L.ptr(w_keras), L.ptr(wf), cin, cout, st)
+            L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wf), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
+        else:
+            wp = self._aempty(8, cout, 8 * cin)
+            L.call('vv_pack_convT_k4s2', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
+            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, cin, cout, dt))
+            L.call('vv_convT3d_k4s2_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
+        return y
 
     # ------------------------------------------------------------------ one step
     def step(self, x, y, eps=None, drop_mask=None, drop_scale=1.0):
@@ -183,46 +242,44 @@ class Trainer:
         return stats, metrics, aux
 
     def _encoder_forward(self, x, B):
-        enc, st, f32 = self.enc, _st(), L.VV_F32
+        enc, st, dt = self.enc, _st(), self.dt
         D, fe, act = enc.D, enc.filters, enc.act
         # ---------------- encoder forward (raw conv -> batch stats -> BN + act)
         ec, eh, ebn = [], [], []
         side = D // 2
-        c = self._empty(B, side, side, side, fe[0])
-        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(enc.packed['w0']), None, None, L.ptr(c), B, D, fe[0], 0, f32, st)
+        c = self._aempty(B, side, side, side, fe[0])
+        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(enc.packed['w0']), None, None, L.ptr(c), B, D, fe[0], 0, dt, st)
         h, bn = self._bn_fwd(c, B * side ** 3, fe[0], enc, 'bn0', act)
         ec.append(c); eh.append(h); ebn.append(bn)
         for i in range(1, len(fe) - 1):
-            ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, fe[i - 1], fe[i], f32))
-            c = self._empty(B, side // 2, side // 2, side // 2, fe[i])
-            L.call('vv_conv3d_k4s2_fwd', L.ptr(eh[-1]), L.ptr(enc.packed['w%d' % i]), None, None, L.ptr(c), B, side, fe[i - 1], fe[i],
-                   0, f32, L.ptr(ws), ws.numel(), st)
+            c = self._conv(eh[-1], enc.params['conv%d/kernel' % i], B, side, fe[i - 1], fe[i])
             side //= 2
             h, bn = self._bn_fwd(c, B * side ** 3, fe[i], enc, 'bn%d' % i, act)
             ec.append(c); eh.append(h); ebn.append(bn)
         ne = len(fe) - 1
         K5 = side ** 3 * fe[ne - 1]
-        enc_out = self._dense(eh[-1], enc.packed['w%d' % ne], B, fe[ne], K5)
+        enc_out = self._dense(eh[-1], enc.packed['w%d' % ne], B, fe[ne], K5, f32_out=True)
         return enc_out, (ec, eh, ebn, side, K5)
 
     def _latent_decoder(self, enc_out, y, eps, drop_mask, drop_scale, B, inv_gb):
-        dec, dev, st, f32 = self.dec, self.dev, _st(), L.VV_F32
+        dec, dev, st, dt = self.dec, self.dev, _st(), self.dt
         D, fd, act = dec.D, dec.filters, dec.act
-        # ---------------- latent
+        # ---------------- latent (float32 in both modes; z_act is the decoder's operand)
         Lz = dec.L
         if self.var:
             if eps is None:
                 eps = torch.randn(B, Lz, dtype=torch.float32, device=dev)
-            z, _, kl, _, _ = E.reparam_kl(enc_out, eps, Lz, f32, drop_mask, drop_scale)
+            z, z_act, kl, _, _ = E.reparam_kl(enc_out, eps, Lz, dt, drop_mask, drop_scale)
         else:
             z, kl = enc_out, None
+            z_act = self._cast(z)
             if drop_mask is not None:
                 raise NotImplementedError('latent dropout for the AE class')
 
         # ---------------- decoder forward
         S, ch = dec.S, dec.ch
         lin = S ** 3 * ch
-        c_d0 = self._dense(z, dec.packed['wd'], B, lin, Lz, shift=dec.params['dense/bias'])
+        c_d0 = self._dense(z_act, dec.packed['wd'], B, lin, Lz, shift=dec.params['dense/bias'])
         t0, bn_d0 = self._bn_fwd(c_d0, B, lin, dec, 'bn_dense', act)
         n1 = S ** 3 * fd[0]
         c_d1 = self._dense(t0, dec.packed['w0'], B, n1, lin)
@@ -230,10 +287,7 @@ class Trainer:
         dc_, dh_, dbn = [c_d1], [h_d1], [bn_d1]
         side = S
         for i in range(1, len(fd) - 1):
-            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, fd[i - 1], fd[i], f32))
-            c = self._empty(B, 2 * side, 2 * side, 2 * side, fd[i])
-            L.call('vv_convT3d_k4s2_fwd', L.ptr(dh_[-1]), L.ptr(dec.packed['w%d' % i]), None, None, L.ptr(c), B, side, fd[i - 1], fd[i],
-                   0, f32, L.ptr(ws), ws.numel(), st)
+            c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i])
             side *= 2
             h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
             dc_.append(c); dh_.append(h); dbn.append(bn)
@@ -243,7 +297,7 @@ class Trainer:
         stats = self._empty(B, 4)
         ws = self.ws.get(L.load().vv_convT3d_final_bce_workspace_bytes(B, side))
         L.call('vv_convT3d_final_bce_fwd', L.ptr(dh_[-1]), L.ptr(w5), L.ptr(y), L.ptr(probs), None, L.ptr(stats), B, side, fd[nd - 1],
-               0.6, 1e-7, f32, L.ptr(ws), ws.numel(), st)
+               0.6, 1e-7, dt, L.ptr(ws), ws.numel(), st)
         metrics = E.shape_metrics(stats)
 
         # ---------------- backward: decoder tail
@@ -251,34 +305,30 @@ class Trainer:
         L.call('vv_bce_bwd', L.ptr(probs), L.ptr(y), L.ptr(dlogit), B, D ** 3, 0.6, 1e-7, inv_gb, st)
         cl = fd[nd - 1]
         self._wgrad_conv(dlogit, dh_[-1], self._g('dec/convT%d/kernel' % nd), B, D, 1, cl)        # [64 taps][cl] = Keras [4,4,4,1,cl]
-        w5p = self._empty(cl, 64)
-        L.call('vv_pack_conv_k4', L.ptr(w5), L.ptr(w5p), 1, cl, f32, st)
-        dh = self._empty(B, side, side, side, cl)
-        L.call('vv_conv3d_first_fwd', L.ptr(dlogit), L.ptr(w5p), None, None, L.ptr(dh), B, D, cl, 0, f32, st)
+        w5p = self._aempty(cl, 64)
+        L.call('vv_pack_conv_k4', L.ptr(w5), L.ptr(w5p), 1, cl, dt, st)
+        dh = self._aempty(B, side, side, side, cl)
+        L.call('vv_conv3d_first_fwd', L.ptr(dlogit), L.ptr(w5p), None, None, L.ptr(dh), B, D, cl, 0, dt, st)
         for i in range(nd - 1, 0, -1):                       # stride-2 transposed convs
             cin, cout = fd[i - 1], fd[i]
             dcv = self._bn_bwd(dc_[i], dh, dbn[i], B * side ** 3, 'dec/bnT%d/gamma' % i, 'dec/bnT%d/beta' % i, act)
             wk = dec.params['convT%d/kernel' % i]            # Keras [4,4,4,cout,cin]
             self._wgrad_conv(dcv, dh_[i - 1], self._g('dec/convT%d/kernel' % i), B, side, cout, cin)
-            wp = self._empty(cin, 64 * cout)                 # read as a forward conv kernel [4,4,4,Cin_c=cout,Cout_c=cin]
-            L.call('vv_pack_conv_k4', L.ptr(wk), L.ptr(wp), cout, cin, f32, st)
-            ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, cout, cin, f32))
-            dh = self._empty(B, side // 2, side // 2, side // 2, cin)
-            L.call('vv_conv3d_k4s2_fwd', L.ptr(dcv), L.ptr(wp), None, None, L.ptr(dh), B, side, cout, cin, 0, f32, L.ptr(ws), ws.numel(), st)
+            dh = self._conv(dcv, wk, B, side, cout, cin)     # read as a forward conv kernel [4,4,4,Cin_c=cout,Cout_c=cin]
             side //= 2
         # D1 (dense panel over the S^3 seed)
         dcv = self._bn_bwd(c_d1, dh, bn_d1, B * S ** 3, 'dec/bnT0/gamma', 'dec/bnT0/beta', act)
         dpanel = self._empty(n1, lin)
         self._wgrad_dense(dcv, t0, dpanel, B, n1, lin)
         L.call('vv_unpack_convT_dense_grad', L.ptr(dpanel), L.ptr(self._g('dec/convT0/kernel')), S, ch, fd[0], st)
-        w0t = self._empty(lin, n1)
-        L.call('vv_transpose_f32', L.ptr(dec.packed['w0']), L.ptr(w0t), n1, lin, st)
-        dt0 = self._dense(dcv, w0t, B, lin, n1)
+        w0f = self._empty(n1, lin)
+        L.call('vv_pack_convT_k4s1_dense', L.ptr(dec.params['convT0/kernel']), L.ptr(w0f), S, ch, fd[0], L.VV_F32, st)
+        dt0 = self._dense(dcv, self._transposed_panel(w0f, n1, lin), B, lin, n1)
         # D0 (Dense + bias)
         dcv0 = self._bn_bwd(c_d0, dt0, bn_d0, B, 'dec/bn_dense/gamma', 'dec/bn_dense/beta', act)
-        L.call('vv_colsum', L.ptr(dcv0), L.ptr(self._g('dec/dense/bias')), B, lin, st)
-        self._wgrad_dense(z, dcv0, self._g('dec/dense/kernel'), B, Lz, lin)
-        dz = self._dense(dcv0, dec.params['dense/kernel'], B, Lz, lin)      # Keras [L][lin] is the [N][K] panel of the data gradient
+        L.call('vv_colsum', L.ptr(dcv0), L.ptr(self._g('dec/dense/bias')), B, lin, self._dt(dcv0), st)
+        self._wgrad_dense(z_act, dcv0, self._g('dec/dense/kernel'), B, Lz, lin)
+        dz = self._dense(dcv0, self._cast(dec.params['dense/kernel']), B, Lz, lin, f32_out=True)   # Keras [L][lin] is the [N][K] panel of the data gradient
 
         # ---------------- backward: latent
         if self.var:
@@ -293,7 +343,7 @@ class Trainer:
         return kl, stats, metrics, de
 
     def _encoder_backward(self, x, de, est, B):
-        enc, st, f32 = self.enc, _st(), L.VV_F32
+        enc, st = self.enc, _st()
         D, fe, act = enc.D, enc.filters, enc.act
         ec, eh, ebn, Sside_e, K5 = est
         ne = len(fe) - 1
@@ -302,20 +352,16 @@ class Trainer:
         dpanel = self._empty(E_out, K5)
         self._wgrad_dense(de, eh[-1], dpanel, B, E_out, K5)
         L.call('vv_unpack_meanpool_grad', L.ptr(dpanel), L.ptr(self._g('enc/conv%d/kernel' % ne)), Sside_e, fe[ne - 1], E_out, st)
-        wet = self._empty(K5, E_out)
-        L.call('vv_transpose_f32', L.ptr(enc.packed['w%d' % ne]), L.ptr(wet), E_out, K5, st)
-        dh = self._dense(de, wet, B, K5, E_out)
+        wef = self._empty(E_out, K5)
+        L.call('vv_pack_conv_k4s1_meanpool', L.ptr(enc.params['conv%d/kernel' % ne]), L.ptr(wef), Sside_e, fe[ne - 1], E_out, L.VV_F32, st)
+        dh = self._dense(self._cast(de), self._transposed_panel(wef, E_out, K5), B, K5, E_out)
         side = Sside_e
         for i in range(ne - 1, 0, -1):                       # stride-2 convs
             cin, cout = fe[i - 1], fe[i]
             dcv = self._bn_bwd(ec[i], dh, ebn[i], B * side ** 3, 'enc/bn%d/gamma' % i, 'enc/bn%d/beta' % i, act)
             wk = enc.params['conv%d/kernel' % i]             # Keras [4,4,4,cin,cout]
             self._wgrad_conv(eh[i - 1], dcv, self._g('enc/conv%d/kernel' % i), B, 2 * side, cin, cout)
-            wp = self._empty(8, cin, 8 * cout)               # read as a transposed kernel [4,4,4,Cout_T=cin,Cin_T=cout]
-            L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(wp), cout, cin, f32, st)
-            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, cout, cin, f32))
-            dh = self._empty(B, 2 * side, 2 * side, 2 * side, cin)
-            L.call('vv_convT3d_k4s2_fwd', L.ptr(dcv), L.ptr(wp), None, None, L.ptr(dh), B, side, cout, cin, 0, f32, L.ptr(ws), ws.numel(), st)
+            dh = self._convT(dcv, wk, B, side, cout, cin)    # read as a transposed kernel [4,4,4,Cout_T=cin,Cin_T=cout]
             side *= 2
         dcv = self._bn_bwd(ec[0], dh, ebn[0], B * side ** 3, 'enc/bn0/gamma', 'enc/bn0/beta', act)
         self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0])

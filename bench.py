@@ -115,8 +115,6 @@ def main():
     from voxvae import engine as E
     from voxvae import synthetic as syn
     from voxvae import workload
-    if a.mode == 'train':
-        a.dtype = 'f32'            # training runs on the exact-f32 MFMA path this round
     voxvae.set_default_dtype(a.dtype)
     voxvae.set_default_device(dev)
     import src.module.nolbo as nolbo

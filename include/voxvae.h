@@ -185,34 +185,36 @@ int vv_sampling(const float *mu, const float *logvar, const float *eps, float *o
  * biased variance, rstd = 1/sqrt(var+eps), folded scale = gamma*rstd, shift = beta - mean*scale; moving statistics
  * updated in place with `momentum` (Keras 0.99) when the pointers are non-NULL. */
 size_t vv_bn_workspace_bytes(long rows, int channels);
-int vv_bn_train_stats(const float *x, long rows, int channels, const float *gamma, const float *beta, float eps,
+int vv_bn_train_stats(const void *x, long rows, int channels, const float *gamma, const float *beta, float eps,
                       float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
-                      float *moving_mean, float *moving_var, void *workspace, size_t workspace_bytes, void *stream);
+                      float *moving_mean, float *moving_var, int dtype, void *workspace, size_t workspace_bytes,
+                      void *stream);
 /* y = act(x*scale + shift) */
-int vv_bn_act_fwd(const float *x, const float *scale, const float *shift, float *y, long rows, int channels, int act,
-                  void *stream);
+int vv_bn_act_fwd(const void *x, const float *scale, const float *shift, void *y, long rows, int channels, int act,
+                  int dtype, void *stream);
 /* Backward of act(BN(x)): given dy = dL/dy, writes dgamma, dbeta [channels] and dx = dL/dx [rows][channels]. */
-int vv_bn_act_bwd(const float *x, const float *dy, const float *scale, const float *shift, const float *mean,
-                  const float *rstd, float *dgamma, float *dbeta, float *dx, long rows, int channels, int act,
-                  void *workspace, size_t workspace_bytes, void *stream);
+int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, const float *shift, const float *mean,
+                  const float *rstd, float *dgamma, float *dbeta, void *dx, long rows, int channels, int act,
+                  int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Weight gradients as reduction-over-rows GEMMs on the exact-f32 MFMA: dw[m][n] = sum_r a[r][m] * g[r][n]. */
+/* Weight gradients as reduction-over-rows GEMMs on the exact-f32 MFMA: dw[m][n] = sum_r a[r][m] * g[r][n].  The operands
+ * may be float32 or bf16 independently (*_dtype; bf16 is widened when staged); dw is always float32. */
 size_t vv_wgrad_workspace_bytes(long rows, int m, int n);
-int vv_wgrad_dense(const float *a, const float *g, float *dw, long rows, int m, int n, int lda, void *workspace,
-                   size_t workspace_bytes, void *stream);
+int vv_wgrad_dense(const void *a, const void *g, float *dw, long rows, int m, int n, int lda, int a_dtype, int g_dtype,
+                   void *workspace, size_t workspace_bytes, void *stream);
 /* a[r][(t,ci)] = src[b, 2o-1+t, ci] gathered over the half-size grid (zero in the SAME padding); g [B*(side/2)^3][cout].
  * Conv3D k4 s2 (src = layer input, g = dL/d(conv out)): dw = Keras [4,4,4,cin,cout].  Conv3DTranspose k4 s2 (src =
  * dL/d(out) on the big grid, g = layer input): dw = Keras [4,4,4,Cout,Cin] with (cin, cout) := (Cout, Cin).
  * cin == 1 (first conv / last transposed conv) or cin % 64 == 0. */
-int vv_wgrad_conv_k4s2(const float *src, const float *g, float *dw, int batch, int side, int cin, int cout,
-                       void *workspace, size_t workspace_bytes, void *stream);
+int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int batch, int side, int cin, int cout, int src_dtype,
+                       int g_dtype, void *workspace, size_t workspace_bytes, void *stream);
 /* Adjoints of vv_pack_conv_k4s1_meanpool / vv_pack_convT_k4s1_dense: panel gradient -> Keras kernel gradient. */
 int vv_unpack_meanpool_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream);
 int vv_unpack_convT_dense_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream);
 /* out[cols][rows] = in[rows][cols]^T (panel transposes for the dense-panel data gradients). */
 int vv_transpose_f32(const float *in, float *out, int rows, int cols, void *stream);
 /* out[c] = sum_r x[r][c] (Dense bias gradient). */
-int vv_colsum(const float *x, float *out, long rows, int cols, void *stream);
+int vv_colsum(const void *x, float *out, long rows, int cols, int dtype, void *stream);
 
 /* dlogit = d(mean_b binary_loss_b)/dlogit through sigmoid and the epsilon clip (function.py:73-82). */
 int vv_bce_bwd(const float *probs, const float *target, float *dlogit, int batch, long voxels, float gamma, float epsilon,
@@ -224,6 +226,10 @@ int vv_reparam_kl_bwd(const float *enc_out, const float *eps, const float *dz, c
  * lr_t = lr sqrt(1-b2^t)/(1-b1^t) computed by the caller (nolbo.py:1402, 1441). */
 int vv_adam_step(float *param, const float *grad, float *m, float *v, long n, float lr_t, float beta1, float beta2,
                  float epsilon, void *stream);
+
+/* dst[i] = (dst type) src[i] between float32 and bf16 (round to nearest even): operand casts of the mixed-precision
+ * training step. */
+int vv_convert(const void *src, void *dst, long n, int src_dtype, int dst_dtype, void *stream);
 
 /* ---- bit-packed occupancy grids (modelnet_dataset.py:74-91 keeps float32 grids on the host and copies a batch per
  * iteration; 32^3 voxels are 4 KiB as bits).  Voxel v of a sample is bit (v & 7) of byte v >> 3.

@@ -8,10 +8,10 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _setup(D, Lz, var, B, seed=0):
+def _setup(D, Lz, var, B, seed=0, dtype='f32'):
     import voxvae
     from voxvae import synthetic as syn
-    voxvae.set_default_dtype('f32')
+    voxvae.set_default_dtype(dtype)
     voxvae.set_default_device(DEV)
     import src.module.nolbo as nolbo
     cfg = syn.make_config(D, Lz, var)
@@ -129,3 +129,38 @@ def test_custom_latent_step_matches_builtin_vae_step():
         a, b = cust.grads.views[n].cpu().numpy(), g.cpu().numpy()
         tol = 1e-5 if n == 'dec/dense/bias' else 2e-5 * np.abs(b).max() + 1e-9     # a bias in front of BatchNorm: true gradient 0
         assert np.abs(a - b).max() <= tol, n
+
+
+@pytest.mark.parametrize('D,Lz,var,B', [(32, 64, True, 8), (32, 64, False, 4)])
+def test_bf16_mixed_precision_fit_tracks_the_oracle(D, Lz, var, B):
+    """Mixed-precision step (bf16 activations / activation gradients / MFMA operands, float32 master weights, statistics,
+    losses and weight-gradient accumulation) against the float64 autograd oracle.  Tolerances are those of bf16 (8
+    mantissa bits, errors accumulate over ten layers): losses 1 %, every gradient tensor within 6 % in the Frobenius
+    norm and pointing the same way (cosine > 0.995)."""
+    from oracle import torch_oracle as to
+    cfg, ep, dp, model, x, eps = _setup(D, Lz, var, B, dtype='bf16')
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=var)
+    out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
+    torch.cuda.synchronize()
+    vals = [float(v) for v in out]
+    if var:
+        assert abs(vals[0] - ref['loss_kl']) <= 1e-2 * max(1.0, abs(ref['loss_kl']))
+        vals = vals[1:]
+    assert abs(vals[0] - ref['loss_shape']) <= 1e-2 * abs(ref['loss_shape'])
+    assert abs(vals[1] - ref['pr']) < 1e-2 and abs(vals[2] - ref['rc']) < 1e-2
+    tr = model._trainer
+    assert tr.dt == 1 and tr.grads.views['enc/conv1/kernel'].dtype == torch.float32
+    worst, cos = {}, {}
+    for name, r in ref['grads'].items():
+        if name == 'dec/dense/bias':
+            continue
+        g = tr.grads.views[name].cpu().numpy().astype(np.float64)
+        worst[name] = float(np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-30))
+        cos[name] = float((g * r).sum() / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30))
+    bad = {k: (worst[k], cos[k]) for k in worst if worst[k] > 6e-2 or cos[k] < 0.995}
+    assert not bad, 'bf16 gradient drift (rel Frobenius error, cosine): %s' % bad
+    print('\n[bf16 fit D%d var%d] worst rel err %.3f (%s), min cosine %.5f' % (D, var, max(worst.values()), max(worst, key=worst.get), min(cos.values())))
+    l0 = vals[0]
+    for _ in range(4):
+        out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
+    assert float(out[1 if var else 0]) < l0
