@@ -2,6 +2,8 @@
 // activation backward, weight gradients as reduction-over-rows GEMMs on the exact-f32 MFMA, BCE / reparameterisation
 // backward, Adam.  Data gradients reuse the forward implicit-GEMM kernels (the data gradient of a stride-2 conv IS the
 // transposed conv with the same Keras kernel array, and vice versa).  float32 only this round.  gfx950.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -282,6 +284,141 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- bf16 weight gradients on v_mfma_f32_32x32x16_bf16.  Both operands of dW = A^T G are k-strided (k = the row index
+// r): the LDS tiles stay row-major as staged, [column block of 32][row][32 bf16] (64-byte rows, so the 32 lanes of a
+// half cover 256 B exactly once), and the MFMA fragments are read with the hardware transpose ds_read_b64_tr_b16:
+// lane 4q+p of a 16-lane group supplies row q / columns 4p..4p+3 of a 4 x 16 block and receives column (lane & 15) of
+// the 4 rows -- two reads give the 8 consecutive k of a lane.  128 x 128 tile per 256-thread workgroup (2 x 2 waves of
+// 64 x 64), 64-row chunks staged by LDS-DMA into a 2-deep ring (zeros for padded taps / rows past R through the
+// buffer range check), split over the reduction into slabs summed in fixed order by wgrad_reduce_kernel.
+struct WgradBArgs {
+    const void *A, *G;
+    float *slabs;
+    long R;
+    int M, N, lda, din_log2, cin, rows_per_split;
+    unsigned a_bytes, g_bytes;
+};
+
+typedef __attribute__((address_space(3))) void *wg_lptr_t;
+typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned wg_u32x2;
+
+__device__ __forceinline__ void wg_dma16(wg_u32x4 rsrc, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ wg_u32x4 wg_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    wg_u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+template <int AMODE>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) {
+    constexpr int BM = 128, BN = 128, BR = 64, OPB = BR * 128 * 2;        // one operand chunk: 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // [2 stages][A | G]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + BN - 1) / BN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long r_begin = (long)blockIdx.y * a.rows_per_split;
+    const long r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
+    const int li = a.din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
+    const wg_u32x4 rsa = wg_rsrc(a.A, a.a_bytes), rsg = wg_rsrc(a.G, a.g_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(wg_lptr_t)smem;
+
+    // staging: piece = (column block cb, 16-row group rg): 16 rows x 64 B; 16 pieces per operand, 4 per wave each
+    const int prow = lane >> 2, pch = lane & 3;
+    auto stage = [&](long rc, int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i, cb = piece >> 2, rg = piece & 3;
+            const long r = rc + rg * 16 + prow;
+            const int mcol = m0 + cb * 32, ncol = n0 + cb * 32;
+            unsigned va = 0xFFFFFFF0u, vg = 0xFFFFFFF0u;
+            if (r < r_end) {
+                if (mcol < a.M) {
+                    if (AMODE == 0) {
+                        va = (unsigned)((r * a.lda + mcol + pch * 8) * 2);
+                    } else {
+                        const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
+                        const long b = r >> (3 * lo);
+                        const int t = mcol / a.cin, ci = mcol - t * a.cin;
+                        const int id = 2 * od - 1 + (t >> 4), ih = 2 * oh - 1 + ((t >> 2) & 3), iw = 2 * ow - 1 + (t & 3);
+                        if ((unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
+                            va = (unsigned)((((((b << li) + id << li) + ih << li) + iw) * a.cin + ci + pch * 8) * 2);
+                    }
+                }
+                if (ncol < a.N) vg = (unsigned)((r * a.N + ncol + pch * 8) * 2);
+            }
+            const unsigned dst = lds0 + st * (2 * OPB) + cb * 4096 + rg * 1024;
+            wg_dma16(rsa, va, dst);
+            wg_dma16(rsg, vg, dst + OPB);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // transposed-read address of this lane inside a column block, for k-step 0: row 8 fh + q, columns 16 (g & 1) + 4p
+    const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const unsigned troff = ((g4 >> 1) * 8 + q4) * 64 + ((g4 & 1) * 16 + p4 * 4) * 2;
+    auto frag = [&](unsigned base) -> bf16x8 {       // base = operand + column block + k-step: rows +0..3 then +4..7
+        wg_u32x2 lo2, hi2;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo2), "=&v"(hi2) : "v"(base + troff) : "memory");
+        wg_u32x4 v = {lo2[0], lo2[1], hi2[0], hi2[1]};
+        return *reinterpret_cast<bf16x8 *>(&v);
+    };
+
+    long rc = r_begin;
+    int st = 0;
+    if (rc < r_end) stage(rc, 0);
+    for (; rc < r_end; rc += BR, st ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // chunk landed for everyone; previous chunk's reads are done
+        if (rc + BR < r_end) stage(rc + BR, st ^ 1);
+        const unsigned sa = lds0 + st * (2 * OPB), sg = sa + OPB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fg[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = frag(sa + (wm * 2 + t) * 4096 + ks * 1024);
+                fg[t] = frag(sg + (wn * 2 + t) * 4096 + ks * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);   // D[m][n]
+        }
+    }
+    const int fr = lane & 31, fh = lane >> 5;
+    float *slab = a.slabs + (size_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n0 + (wn * 2 + j) * 32 + fr;
+            if (nn >= a.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh;
+                if (m < a.M) slab[(size_t)m * a.N + nn] = acc[i][j][q];
+            }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, long n, int splits, float alpha,
                                     int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -505,6 +642,29 @@ WgradPlan wgrad_plan(long R, int M, int N) {
     return p;
 }
 
+// bf16 kernel: 128 x 128 tiles, 64-row chunks
+WgradPlan wgrad_plan_bf16(long R, int M, int N) {
+    WgradPlan p;
+    p.bn = 128;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    long chunks = (R + 63) / 64;
+    long splits = 1;
+    while (tiles * splits < 512 && splits * 2 <= chunks && splits < 256) splits *= 2;
+    p.rps = (int)(((chunks + splits - 1) / splits) * 64);
+    p.splits = (int)((R + p.rps - 1) / p.rps);
+    p.ws = (size_t)p.splits * M * N * sizeof(float);
+    return p;
+}
+
+bool wgrad_bf16_ok(const void *A, const void *G, long R, int M, int N, int lda, int cin, int amode, size_t a_elems) {
+    if (getenv("VV_WGRAD_F32")) return false;
+    if (M % 32 || N % 32) return false;
+    if (amode == 0 && lda % 8) return false;
+    if (amode == 1 && cin % 64) return false;
+    if (a_elems * 2 >= 0xFFFFFFF0ull || (size_t)R * N * 2 >= 0xFFFFFFF0ull) return false;
+    return vv_aligned16(A) && vv_aligned16(G);
+}
+
 template <int AMODE>
 int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha, int accumulate, hipStream_t st) {
     const int tiles = ((a.M + 63) / 64) * ((a.N + p.bn - 1) / p.bn);
@@ -514,17 +674,40 @@ int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha
     VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, a.slabs, out, n, p.splits, alpha, accumulate);
     return vv_launch_status();
 }
+
+template <int AMODE>
+int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipStream_t st) {
+    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        return true;
+    }();
+    (void)attr;
+    VV_LAUNCH((wgrad_bf16_kernel<AMODE>), dim3(tiles, p.splits), dim3(256), 65536, st, a);
+    const long n = (long)a.M * a.N;
+    VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, a.slabs, out, n, p.splits, 1.f, 0);
+    return vv_launch_status();
+}
 }  // namespace
 
-VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) { return wgrad_plan(rows, m, n).ws; }
+VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) {
+    const size_t a = wgrad_plan(rows, m, n).ws, b = wgrad_plan_bf16(rows, m, n).ws;     // the caller need not know which kernel runs
+    return a > b ? a : b;
+}
 
 VV_EXPORT int vv_wgrad_dense(const void *a, const void *g, float *dw, long rows, int m, int n, int lda, int a_dtype, int g_dtype,
                              void *workspace, size_t workspace_bytes, void *stream) {
     if (!a || !g || !dw) return VV_ERR_NULL;
     if ((a_dtype != VV_F32 && a_dtype != VV_BF16) || (g_dtype != VV_F32 && g_dtype != VV_BF16)) return VV_ERR_DTYPE;
     if (rows <= 0 || m <= 0 || n <= 0 || m % 4 || n % 4 || lda % 4) return VV_ERR_SHAPE;
+    if (!workspace || workspace_bytes < vv_wgrad_workspace_bytes(rows, m, n)) return VV_ERR_WORKSPACE;
+    if (a_dtype == VV_BF16 && g_dtype == VV_BF16 && wgrad_bf16_ok(a, g, rows, m, n, lda, 0, 0, (size_t)rows * lda)) {
+        const WgradPlan pb = wgrad_plan_bf16(rows, m, n);
+        WgradBArgs wb{a, g, reinterpret_cast<float *>(workspace), rows, m, n, lda, 0, 0, pb.rps, (unsigned)((size_t)rows * lda * 2),
+                      (unsigned)((size_t)rows * n * 2)};
+        return launch_wgrad_bf16<0>(wb, pb, dw, reinterpret_cast<hipStream_t>(stream));
+    }
     const WgradPlan p = wgrad_plan(rows, m, n);
-    if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
     WgradArgs w{a, g, reinterpret_cast<float *>(workspace), rows, m, n, lda, 0, 0, p.rps, a_dtype == VV_BF16, g_dtype == VV_BF16};
     return launch_wgrad<0>(w, p, dw, 1.f, 0, reinterpret_cast<hipStream_t>(stream));
 }
@@ -538,11 +721,18 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
     const int o = side / 2;
     const long rows = (long)batch * o * o * o;
     const int m = 64 * cin;
+    if (!workspace || workspace_bytes < vv_wgrad_workspace_bytes(rows, m, cout)) return VV_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t src_elems = (size_t)batch * side * side * side * cin;
+    if (cin != 1 && src_dtype == VV_BF16 && g_dtype == VV_BF16 && wgrad_bf16_ok(src, g, rows, m, cout, 0, cin, 1, src_elems)) {
+        const WgradPlan pb = wgrad_plan_bf16(rows, m, cout);
+        WgradBArgs wb{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, pb.rps,
+                      (unsigned)(src_elems * 2), (unsigned)((size_t)rows * cout * 2)};
+        return launch_wgrad_bf16<1>(wb, pb, dw, st);
+    }
     const WgradPlan p = wgrad_plan(rows, m, cout);
-    if (!workspace || workspace_bytes < p.ws) return VV_ERR_WORKSPACE;
     WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps, src_dtype == VV_BF16,
                 g_dtype == VV_BF16};
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return cin == 1 ? launch_wgrad<2>(w, p, dw, 1.f, 0, st) : launch_wgrad<1>(w, p, dw, 1.f, 0, st);
 }
 

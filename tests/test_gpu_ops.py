@@ -290,3 +290,59 @@ def test_conv3d_k4s2_direct(L, B, side, act):
     torch.cuda.synchronize()
     d = (y.float() - y2.float()).abs().max().item()
     assert d <= 2e-2, 'direct vs implicit-GEMM: %.3e' % d
+
+
+def _wgrad_conv_ref(src, g):
+    """dW[t][ci][co] = sum over (b, o) of src[b, 2o-1+t, ci] * g[b, o, co] (zero padding), float64."""
+    B, S, _, _, cin = src.shape
+    o, cout = S // 2, g.shape[-1]
+    p = np.zeros((B, S + 2, S + 2, S + 2, cin))
+    p[:, 1:-1, 1:-1, 1:-1] = src
+    dw = np.zeros((4, 4, 4, cin, cout))
+    for td in range(4):
+        for th in range(4):
+            for tw in range(4):
+                win = p[:, td:td + 2 * o:2, th:th + 2 * o:2, tw:tw + 2 * o:2]          # [B,o,o,o,cin]
+                dw[td, th, tw] = np.einsum('bdhwi,bdhwo->io', win, g)
+    return dw
+
+
+@pytest.mark.parametrize('adt,gdt', [('f32', 'f32'), ('bf16', 'bf16'), ('bf16', 'f32')])
+def test_wgrad_kernels(L, adt, gdt, monkeypatch):
+    """Weight gradients dW = A^T G: float32 operands on the exact-f32 MFMA, bf16 operands on the bf16 MFMA with
+    transposed LDS reads (ds_read_b64_tr_b16), mixed operands widened onto the f32 path.  Dense (ragged M / N / rows) and
+    the strided-conv gather (cin = 64: a 128-column tile spans two taps; cin = 128)."""
+    rng = np.random.default_rng(7)
+    T = {'f32': torch.float32, 'bf16': torch.bfloat16}
+    rnd = lambda a, d: _bf16_round(a) if d == 'bf16' else a.astype(np.float32)
+    for rows, m, n in ((300, 160, 96), (64, 128, 4096), (1000, 32, 32)):
+        a = rnd(rng.standard_normal((rows, m)).astype(np.float32), adt)
+        g = rnd(rng.standard_normal((rows, n)).astype(np.float32), gdt)
+        ref = a.astype(np.float64).T @ g.astype(np.float64)
+        ad, gd = _dev(a, T[adt]), _dev(g, T[gdt])
+        out = torch.full((m, n), 7.0, dtype=torch.float32, device=DEV)
+        ws = torch.empty(L.load().vv_wgrad_workspace_bytes(rows, m, n), dtype=torch.uint8, device=DEV)
+        L.call('vv_wgrad_dense', L.ptr(ad), L.ptr(gd), L.ptr(out), rows, m, n, m, L.DTYPES[adt], L.DTYPES[gdt], L.ptr(ws), ws.numel(), _st())
+        torch.cuda.synchronize()
+        err = np.abs(out.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('dense', rows, m, n, err)
+    for B, side, cin, cout in ((3, 8, 64, 128), (2, 4, 128, 64), (5, 8, 64, 32)):
+        src = rnd(rng.standard_normal((B, side, side, side, cin)).astype(np.float32), adt)
+        o = side // 2
+        g = rnd(rng.standard_normal((B, o, o, o, cout)).astype(np.float32), gdt)
+        ref = _wgrad_conv_ref(src.astype(np.float64), g.astype(np.float64))
+        sd, gd = _dev(src, T[adt]), _dev(g, T[gdt])
+        out = torch.full((4, 4, 4, cin, cout), 7.0, dtype=torch.float32, device=DEV)
+        ws = torch.empty(L.load().vv_wgrad_workspace_bytes(B * o ** 3, 64 * cin, cout), dtype=torch.uint8, device=DEV)
+        L.call('vv_wgrad_conv_k4s2', L.ptr(sd), L.ptr(gd), L.ptr(out), B, side, cin, cout, L.DTYPES[adt], L.DTYPES[gdt], L.ptr(ws),
+               ws.numel(), _st())
+        torch.cuda.synchronize()
+        err = np.abs(out.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('conv', B, side, cin, cout, err)
+    if adt == gdt == 'bf16':      # same operands through the widening f32 kernel: the two paths agree to float32 rounding
+        monkeypatch.setenv('VV_WGRAD_F32', '1')
+        out2 = torch.empty_like(out)
+        L.call('vv_wgrad_conv_k4s2', L.ptr(sd), L.ptr(gd), L.ptr(out2), B, side, cin, cout, L.DTYPES[adt], L.DTYPES[gdt], L.ptr(ws),
+               ws.numel(), _st())
+        torch.cuda.synchronize()
+        assert (out - out2).abs().max().item() <= 2e-5 * np.abs(ref).max()
