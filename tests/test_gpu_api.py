@@ -401,3 +401,89 @@ def test_keras_named_checkpoint_interop_and_losses():
     assert len(reg) == 7                                                   # dense kernel + bias, 5 transposed-conv kernels
     np.testing.assert_allclose(sum(float(r) for r in reg), 0.0005 * sum(float((p[k].astype(np.float64) ** 2).sum()) for k in p
                                if k.endswith('/kernel') or k == 'dense/bias'), rtol=1e-5)
+
+
+def test_surveyed_edge_cases():
+    """SURVEY §8(c) edge cases: all-empty / all-full grids, TP+FP = 0 (precision -> 0 through the 1e-10 guard), logits at
+    and beyond the float32 sigmoid saturation (|l| ~ 15.94, 16.7, 20), and the where(z == 0) quirk of the missing-latent
+    path (an unmasked latent that is EXACTLY zero is replaced too, nolbo.py:1481-1482)."""
+    import ctypes
+    import voxvae
+    from voxvae import lib as L
+    from voxvae import synthetic as syn
+    import src.module.function as F
+    import src.module.nolbo as nolbo
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- saturation ladder through the last layer: one live channel, every tap = l/8 -> logits l*k/8, k in {1,2,4,8}
+    for form in ('box', 'sweep'):
+        os.environ['VV_FINAL_BCE'] = form
+        try:
+            for lmax in (15.9424, 16.7, 20.0, -20.0, 127.5):
+                B, side = 2, 8
+                x = np.zeros((B, side, side, side, 64), np.float32); x[..., 0] = 1.0
+                w = np.zeros((4, 4, 4, 1, 64), np.float32); w[..., 0, 0] = lmax / 8.0
+                for y_val in (0.0, 1.0):                      # all-empty and all-full targets
+                    y = np.full((B, 16, 16, 16, 1), y_val, np.float32)
+                    lg = no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2)
+                    p32 = (1.0 / (1.0 + np.exp(-lg.astype(np.float32)))).astype(np.float32)
+                    q = np.clip(p32, np.float32(1e-7), np.float32(1.0) - np.float32(1e-7))
+                    bce = -(0.6 * y * np.log(q.astype(np.float64)) + 0.4 * (1 - y) * np.log((np.float32(1.0) - q).astype(np.float64))).reshape(B, -1).sum(-1)
+                    yh = (lg >= 0).astype(np.float64)
+                    tp, fp, fn = [(a.reshape(B, -1)).sum(-1) for a in (y * yh, (1 - y) * yh, y * (1 - yh))]
+                    probs = torch.empty(B, 16, 16, 16, 1, device='cuda:0'); stats = torch.empty(B, 4, device='cuda:0')
+                    ws = torch.empty(L.load().vv_convT3d_final_bce_workspace_bytes(B, side), dtype=torch.uint8, device='cuda:0')
+                    xd = torch.from_numpy(x).cuda().to(torch.bfloat16)
+                    wd, yd = torch.from_numpy(w).cuda(), torch.from_numpy(y).cuda()
+                    L.call('vv_convT3d_final_bce_fwd', L.ptr(xd), L.ptr(wd), L.ptr(yd), L.ptr(probs), None, L.ptr(stats), B, side, 64,
+                           0.6, 1e-7, L.VV_BF16, L.ptr(ws), ws.numel(), st)
+                    s = stats.cpu().numpy().astype(np.float64)
+                    # 127.5/8 is exact in bf16; the other ladders round the weight to bf16 first
+                    if lmax == 127.5:
+                        np.testing.assert_allclose(s[:, 0], bce, rtol=2e-4)
+                    np.testing.assert_array_equal(s[:, 1:], np.stack([tp, fp, fn], 1))
+                    out = torch.empty(4, device='cuda:0')
+                    L.call('vv_shape_metrics', L.ptr(stats), L.ptr(out), B, st)
+                    o = out.cpu().numpy()
+                    prr, rcc = no.pr_rc(tp, fp, fn)
+                    np.testing.assert_allclose(o[1:3], [prr, rcc], atol=1e-6)
+                    if (lmax < 0 and y_val == 1.0) or (lmax > 0 and y_val == 0.0):
+                        assert o[1] == 0.0 and (o[2] == 0.0)          # nothing predicted / nothing to recall: guards give 0, not NaN
+        finally:
+            os.environ.pop('VV_FINAL_BCE', None)
+
+    # ---- binary_loss / voxelPrecisionRecall on saturated probabilities (function.py:73-115)
+    l = np.array([[-40.0, -16.7, -15.9424, 0.0, 15.9424, 16.7, 40.0, 3.0]], np.float32)
+    p = (1.0 / (1.0 + np.exp(-l))).astype(np.float32)
+    y = np.array([[1, 0, 1, 1, 0, 1, 0, 1]], np.float32)
+    got = np.array(F.binary_loss(p, y, gamma=0.6))
+    np.testing.assert_allclose(got, no.binary_loss(p, y, gamma=0.6), rtol=1e-5)
+    tp, fp, fn = [np.array(a) for a in F.voxelPrecisionRecall(y, p)]
+    rtp, rfp, rfn = no.voxel_precision_recall(y, p)
+    np.testing.assert_array_equal([tp, fp, fn], [rtp, rfp, rfn])
+
+    # ---- all-empty and all-full INPUT grids through the whole VAE (float32 parity mode) against the numpy oracle
+    voxvae.set_default_dtype('f32')
+    cfg = syn.make_config(16, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(ep); m._decoder.set_weights_dict(dp)
+    x = np.zeros((2, 16, 16, 16, 1), np.float32); x[1] = 1.0
+    eps, cats, oh = syn.make_eps(2, 64), syn.make_category_vectors(40, 64), syn.make_onehot(2, 40)
+    out = m.getEval(inputs=(x, x, oh), category_vectors=cats, _eps=eps)
+    ref = no.vae_get_eval(cfg, ep, dp, (x, x, oh), cats, eps)
+    np.testing.assert_allclose(np.array(out[0]), ref[0], atol=2e-5)
+    np.testing.assert_allclose([float(out[1]), float(out[2]), float(out[3])], [ref[1], ref[2], ref[3]], rtol=2e-4, atol=1e-6)
+
+    # ---- where(z == 0): head output 0 and eps 0 give z == 0 exactly; with an all-ones mask every entry is still replaced
+    dec_cfg = syn.make_config(16, 16, True)['decoder']
+    pc = {'encoder_backbone': {'name': 'bb', 'z_dim': 16}, 'encoder_head': None, 'decoder': dec_cfg}
+    pm = nolbo.nolboSingleObject_VAE(nolbo_structure=pc)
+    head = np.zeros((3, 32), np.float32); head[2, :16] = 0.25                 # sample 2 has a non-zero mean
+    cats12 = syn.make_category_vectors(12, 16)
+    vox = syn.make_voxels(3, 16)
+    pm.getEval(inputs=(head, vox, syn.make_onehot(3, 12)), category_vectors=cats12, missing_prob=0.5,
+               _eps=np.zeros((3, 16), np.float32), _mask=np.ones((3, 16), np.float32), _eps2=np.zeros((3, 16), np.float32))
+    z = np.array(pm._z_category)
+    np.testing.assert_allclose(z[:2], np.tile(cats12.mean(0), (2, 1)), atol=1e-6)
+    np.testing.assert_allclose(z[2], 0.25, atol=1e-7)
