@@ -531,8 +531,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
-// Sums the split-K slabs in split order, applies the folded BN + activation, scatters to the output.
-template <int MODE>
+// Sums the split-K slabs in split order, applies the folded BN + activation, scatters to the output: one channel quad
+// per thread (float4 slab reads, float4 folded-BN reads, one 8- / 16-byte store), activation hoisted out of the loop.
+template <int MODE, int ACT>
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, int nsplit, int nparity) {
     const int n4 = a.N >> 2;
     const size_t total = (size_t)nparity * a.M * n4;
@@ -543,13 +544,26 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, 
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int sp = 0; sp < nsplit; ++sp)
             s += *reinterpret_cast<const f32x4 *>(a.partial + (((size_t)(sp * nparity + parity) * a.M + m) * a.N + c4 * 4));
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.scale) sc = *reinterpret_cast<const f32x4 *>(a.scale + c4 * 4);
+        if (a.shift) sh = *reinterpret_cast<const f32x4 *>(a.shift + c4 * 4);
         const size_t o = out_row<MODE>(a, m, parity) + c4 * 4;
+        f32x4 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = c4 * 4 + q;
-            const float v = vv_apply_act(s[q] * (a.scale ? a.scale[n] : 1.f) + (a.shift ? a.shift[n] : 0.f), a.act);
-            if (a.out_bf16) reinterpret_cast<__bf16 *>(a.Out)[o + q] = static_cast<__bf16>(v);
-            else reinterpret_cast<float *>(a.Out)[o + q] = v;
+            float t = s[q] * sc[q] + sh[q];
+            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = a.out_bf16 ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
+            else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+            else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+            v[q] = t;
+        }
+        if (a.out_bf16) {
+            bf16x4 ob;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ob[q] = static_cast<__bf16>(v[q]);
+            *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(a.Out) + o) = ob;
+        } else {
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(a.Out) + o) = v;
         }
     }
 }
@@ -621,7 +635,12 @@ int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     if (p.split > 1) {
         const size_t total = (size_t)p.nparity * a.M * (a.N / 4);
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        VV_LAUNCH((igemm_splitk_epilogue<MODE>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity);
+        switch (a.act) {
+            case VV_ACT_ELU: VV_LAUNCH((igemm_splitk_epilogue<MODE, VV_ACT_ELU>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity); break;
+            case VV_ACT_RELU: VV_LAUNCH((igemm_splitk_epilogue<MODE, VV_ACT_RELU>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity); break;
+            case VV_ACT_LRELU: VV_LAUNCH((igemm_splitk_epilogue<MODE, VV_ACT_LRELU>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity); break;
+            default: VV_LAUNCH((igemm_splitk_epilogue<MODE, VV_ACT_NONE>), dim3(blocks), dim3(256), 0, st, a, p.split, p.nparity); break;
+        }
     }
     return vv_launch_status();
 }
