@@ -63,6 +63,24 @@ def cpu_baseline(cfg, ep, dp, x, eps, n, min_seconds=10.0, max_passes=50):
                          % (passes, n, x.shape[0], dt)}
 
 
+def cpu_baseline_torch(cfg, ep, dp, x, eps, ref, n=64, min_seconds=5.0, max_passes=20):
+    """Secondary CPU bracket: the same graph on torch-CPU float32 ops (oneDNN convolutions, the library family
+    TF-CPU dispatches to), bounded like the C leg; also cross-checks the two CPU statements against each other."""
+    from oracle import torch_oracle as to
+    n = min(n, x.shape[0])
+    lg, bce, tp, fp, fn = to.eval_forward_f32(cfg, ep, dp, x[:n], eps[:n])          # warm-up + agreement with the C oracle
+    agree = float(np.abs(lg - ref['logits'][:n]).max())
+    passes, dt = 0, 0.0
+    while passes < max_passes and dt < min_seconds:
+        t0 = time.perf_counter()
+        to.eval_forward_f32(cfg, ep, dp, x[:n], eps[:n])
+        dt += time.perf_counter() - t0
+        passes += 1
+    return {'value': n * passes / dt, 'unit': 'reconstructions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'max_logit_diff_vs_c_oracle': agree,
+            'sample': '%d pass(es) over %d samples, torch-CPU float32 (F.conv3d / F.conv_transpose3d), %.1f s' % (passes, n, dt)}
+
+
 def bench_train(a, model, x, eps, world, rank, dev, dist):
     """Training-step throughput (BASELINE.json configs[3]: batch sharded over the ranks, gradients summed by RCCL)."""
     from voxvae import train as T
@@ -175,12 +193,13 @@ def main():
 
     # ---- parity gate + CPU baseline (rank 0, N == 1 only): AFTER the timed region -- the oracle's OpenMP team
     # spin-waits on every host core and would starve the launch thread
-    cpu, iou_delta, logit_err = None, None, None
+    cpu, cpu_torch, iou_delta, logit_err = None, None, None, None
     model._enc_eng.timer = model._dec_eng.timer = None
     pred, stats, metrics, kl = step()
     torch.cuda.synchronize()
     if rank == 0 and world == 1 and a.cpu_samples > 0:
         ref, cpu = cpu_baseline(cfg, ep, dp, xh, epsh, a.cpu_samples)
+        cpu_torch = cpu_baseline_torch(cfg, ep, dp, xh, epsh, ref)
         n = ref['bce'].shape[0]
         s = stats[:n].cpu().numpy().astype(np.float64)
         iou_g = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
@@ -239,7 +258,7 @@ def main():
             'roofline': roof,
             'heaviest_mfma_layer': mfma_layer,
             'layer_ms': breakdown,
-            'cpu_baseline': cpu,
+            'cpu_baseline': cpu, 'cpu_baseline_torch': cpu_torch,
         }
         print(json.dumps(out))
     if dist is not None:

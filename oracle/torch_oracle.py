@@ -143,3 +143,44 @@ def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variatio
     return {'loss_kl': float(kl.detach()), 'loss_shape': float(shape.detach()), 'pr': float(np.mean(tp / (tp + fp + 1e-10))),
             'rc': float(np.mean(tp / (tp + fn + 1e-10))), 'grads': g, 'params': new, 'bn_stats': stats,
             'adam': {'t': t, 'm': m2, 'v': v2}, 'probs': pn}
+
+
+def eval_forward_f32(config, enc_p, dec_p, x, eps):
+    """Inference forward of getEval(missing_prob=0) (nolbo.py:1463-1501) on torch-CPU float32 ops (F.conv3d /
+    F.conv_transpose3d: the oneDNN kernel family TF-CPU dispatches to) -- the secondary CPU bracket of SURVEY §8(d).
+    Returns (logits [B,D,D,D,1], bce [B], tp, fp, fn) as numpy."""
+    enc, dec = config['encoder'], config['decoder']
+    L = config['z_category_dim']
+    f32 = torch.float32
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+    def bn(h, P, pre):
+        sc = T(P[pre + '/gamma']) / torch.sqrt(T(P[pre + '/moving_variance']) + BN_EPS)
+        return h * sc + (T(P[pre + '/beta']) - T(P[pre + '/moving_mean']) * sc)
+
+    with torch.no_grad():
+        h = T(x)
+        fl, st = enc['filter_num_list'], enc['strides_list']
+        for i in range(len(fl) - 1):
+            h = _act(bn(_conv_same(h, T(enc_p['conv%d/kernel' % i]), st[i]), enc_p, 'bn%d' % i), enc['activation'])
+        i = len(fl) - 1
+        e = _conv_same(h, T(enc_p['conv%d/kernel' % i]), st[i]).mean(dim=(1, 2, 3))
+        mu, lv = e[:, :L], torch.clamp(e[:, L:2 * L], -10.0, 10.0)
+        z = mu + torch.sqrt(torch.exp(lv)) * T(eps)
+        side = dec['output_shape'][0] // int(np.prod(dec['strides_list']))
+        ch = max(dec['filter_num_list'][0] // 64, 8)
+        t = _act(bn(z @ T(dec_p['dense/kernel']) + T(dec_p['dense/bias']), dec_p, 'bn_dense'), dec['activation'])
+        t = t.reshape(-1, side, side, side, ch)
+        fl, st = dec['filter_num_list'], dec['strides_list']
+        for i in range(len(fl) - 1):
+            t = _act(bn(_convT_same(t, T(dec_p['convT%d/kernel' % i]), st[i]), dec_p, 'bnT%d' % i), dec['activation'])
+        i = len(fl) - 1
+        logits = _convT_same(t, T(dec_p['convT%d/kernel' % i]), st[i])
+        p = torch.sigmoid(logits)
+        y = T(x)
+        q = torch.clamp(p, 1e-7, 1.0 - 1e-7)
+        B = y.shape[0]
+        bce = -(0.6 * y * torch.log(q) + 0.4 * (1.0 - y) * torch.log(1.0 - q)).reshape(B, -1).sum(-1)
+        yh = (p >= 0.5).to(f32)
+        tp = (y * yh).reshape(B, -1).sum(-1); fp = ((1 - y) * yh).reshape(B, -1).sum(-1); fn = (y * (1 - yh)).reshape(B, -1).sum(-1)
+    return logits.numpy(), bce.numpy(), tp.numpy(), fp.numpy(), fn.numpy()

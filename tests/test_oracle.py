@@ -169,3 +169,18 @@ def test_missing_latent_quirks():
     eps2 = syn.make_eps(3, 64, seed=8)
     idx = g['p5_argmin_masked'].astype(int)
     np.testing.assert_allclose(zc[mask == 0], (cats[idx].astype(np.float64) + eps2)[mask == 0])
+
+
+def test_torch_cpu_f32_bracket_matches_c_oracle():
+    """bench.py's secondary CPU leg (torch float32 ops) and the C oracle are two statements of the same forward."""
+    from oracle import c_oracle as co
+    from oracle import torch_oracle as to
+    cfg = syn.make_config(16, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x, eps = syn.make_voxels(3, 16), syn.make_eps(3, 64)
+    co.build()
+    r = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
+    lg, bce, tp, fp, fn = to.eval_forward_f32(cfg, ep, dp, x, eps)
+    assert np.abs(lg - r['logits']).max() < 2e-4
+    np.testing.assert_allclose(bce, r['bce'], rtol=1e-4)
+    np.testing.assert_array_equal([tp, fp, fn], [r['tp'], r['fp'], r['fn']])
