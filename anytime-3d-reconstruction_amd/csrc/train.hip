@@ -434,6 +434,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
         }
 }
 
+// im2col of a single-channel grid for the k4 s2 SAME window: out[(b,o)][t] = src[b, 2o-1+t] (0 in the padding), bf16.
+// Feeds the bf16 weight-gradient kernel for the two Cin = 1 layers (first conv: src = x; last transposed conv: src =
+// dL/dlogit), whose float32 gather form spent 0.4 ms per layer on scalar tap loads.  One thread = 8 taps (td, th pair,
+// tw 0..3) of one row = one 16-byte store.
+__global__ void im2col_c1_kernel(const float *__restrict__ src, __bf16 *__restrict__ out, int din_log2, long rows) {
+    const int li = din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
+    const long total = rows * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i >> 3;
+        const int gq = (int)(i & 7), td = gq >> 1, th0 = (gq & 1) * 2;
+        const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
+        const long b = r >> (3 * lo);
+        const int id = 2 * od - 1 + td, iw0 = 2 * ow - 1;
+        bf16x8 o;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int ih = 2 * oh - 1 + th0 + rr;
+            const bool okr = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n;
+            const float *p = src + ((((b << li) + id) << li) + ih << li) + iw0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[rr * 4 + e] = static_cast<__bf16>((okr && (unsigned)(iw0 + e) < (unsigned)n) ? p[e] : 0.f);
+        }
+        reinterpret_cast<bf16x8 *>(out)[i] = o;
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, long n, int splits, float alpha,
                                     int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -706,7 +732,9 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
 }  // namespace
 
 VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) {
-    const size_t a = wgrad_plan(rows, m, n).ws, b = wgrad_plan_bf16(rows, m, n).ws;     // the caller need not know which kernel runs
+    const size_t a = wgrad_plan(rows, m, n).ws;     // the caller need not know which kernel runs
+    size_t b = wgrad_plan_bf16(rows, m, n).ws;
+    if (m == 64) b = ((b + 255) & ~(size_t)255) + (size_t)rows * 64 * 2;   // single-channel layers: bf16 im2col rows behind the slabs
     return a > b ? a : b;
 }
 
@@ -744,6 +772,15 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
         WgradBArgs wb{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, pb.rps,
                       (unsigned)(src_elems * 2), (unsigned)((size_t)rows * cout * 2)};
         return launch_wgrad_bf16<1>(wb, pb, dw, st);
+    }
+    if (cin == 1 && g_dtype == VV_BF16 && cout % 32 == 0 && (size_t)rows * 64 * 2 < 0xFFFFFFF0ull && vv_aligned16(g) && !getenv("VV_WGRAD_F32")) {
+        // single input channel: materialise the im2col rows in bf16 behind the slabs, then the dense bf16 kernel
+        const WgradPlan pb = wgrad_plan_bf16(rows, 64, cout);
+        __bf16 *col = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(workspace) + ((pb.ws + 255) & ~(size_t)255));
+        VV_LAUNCH(im2col_c1_kernel, dim3(grid_1d(rows * 8)), dim3(256), 0, st, reinterpret_cast<const float *>(src), col, vv_log2(side), rows);
+        WgradBArgs wb{col, g, reinterpret_cast<float *>(workspace), rows, 64, cout, 64, 0, 0, pb.rps, (unsigned)((size_t)rows * 64 * 2),
+                      (unsigned)((size_t)rows * cout * 2)};
+        return launch_wgrad_bf16<0>(wb, pb, dw, st);
     }
     const WgradPlan p = wgrad_plan(rows, m, cout);
     WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps, src_dtype == VV_BF16,

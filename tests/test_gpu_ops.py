@@ -339,10 +339,27 @@ def test_wgrad_kernels(L, adt, gdt, monkeypatch):
         torch.cuda.synchronize()
         err = np.abs(out.cpu().numpy() - ref).max()
         assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('conv', B, side, cin, cout, err)
+    last = (sd, gd, out, ws, B, side, cin, cout, np.abs(ref).max())
+    # single input channel (first conv / last transposed conv): float32 source grid, g float32 or bf16 (bf16 im2col path)
+    for B, side, cout in ((3, 16, 64), (2, 8, 32)):
+        src = (rng.random((B, side, side, side, 1)) < 0.3).astype(np.float32) * rng.standard_normal((B, side, side, side, 1)).astype(np.float32)
+        if gdt == 'bf16':
+            src = _bf16_round(src)                       # the im2col rows are bf16
+        o = side // 2
+        g = rnd(rng.standard_normal((B, o, o, o, cout)).astype(np.float32), gdt)
+        ref = _wgrad_conv_ref(src.astype(np.float64), g.astype(np.float64))
+        sd, gd = _dev(src), _dev(g, T[gdt])
+        out = torch.full((4, 4, 4, 1, cout), 7.0, dtype=torch.float32, device=DEV)
+        ws = torch.empty(L.load().vv_wgrad_workspace_bytes(B * o ** 3, 64, cout), dtype=torch.uint8, device=DEV)
+        L.call('vv_wgrad_conv_k4s2', L.ptr(sd), L.ptr(gd), L.ptr(out), B, side, 1, cout, L.VV_F32, L.DTYPES[gdt], L.ptr(ws), ws.numel(), _st())
+        torch.cuda.synchronize()
+        err = np.abs(out.cpu().numpy() - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('conv cin=1', B, side, cout, err)
     if adt == gdt == 'bf16':      # same operands through the widening f32 kernel: the two paths agree to float32 rounding
+        sd, gd, out, ws, B, side, cin, cout, refmax = last
         monkeypatch.setenv('VV_WGRAD_F32', '1')
         out2 = torch.empty_like(out)
         L.call('vv_wgrad_conv_k4s2', L.ptr(sd), L.ptr(gd), L.ptr(out2), B, side, cin, cout, L.DTYPES[adt], L.DTYPES[gdt], L.ptr(ws),
                ws.numel(), _st())
         torch.cuda.synchronize()
-        assert (out - out2).abs().max().item() <= 2e-5 * np.abs(ref).max()
+        assert (out - out2).abs().max().item() <= 2e-5 * refmax
