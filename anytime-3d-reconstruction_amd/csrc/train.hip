@@ -578,6 +578,20 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// All variables in ONE launch: the caller supplies a device table of chunks (pointers already offset, <= 16384 elements
+// each); one workgroup per chunk.  Same arithmetic as adam_kernel.
+struct AdamChunk { float *p; const float *g; float *m; float *v; long n; };
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk *__restrict__ table, float lr_t, float b1, float b2, float eps) {
+    const AdamChunk c = table[blockIdx.x];
+    for (long i = threadIdx.x; i < c.n; i += 256) {
+        const float gi = c.g[i];
+        const float mi = b1 * c.m[i] + (1.f - b1) * gi;
+        const float vi = b2 * c.v[i] + (1.f - b2) * gi * gi;
+        c.m[i] = mi; c.v[i] = vi;
+        c.p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 template <typename T>
 __global__ void colsum_kernel(const T *__restrict__ x, float *__restrict__ out, long R, int C) {
     // out[c] = sum_r x[r][c] (Dense bias gradient; R = batch, small)
@@ -834,6 +848,14 @@ VV_EXPORT int vv_adam_step(float *param, const float *grad, float *m, float *v, 
     if (n <= 0) return VV_ERR_SHAPE;
     VV_LAUNCH(adam_kernel, dim3(grid_1d(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad, m, v, n, lr_t, beta1,
               beta2, epsilon);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_adam_step_multi(const void *chunk_table, int nchunks, float lr_t, float beta1, float beta2, float epsilon, void *stream) {
+    if (!chunk_table) return VV_ERR_NULL;
+    if (nchunks <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(adam_multi_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+              reinterpret_cast<const AdamChunk *>(chunk_table), lr_t, beta1, beta2, epsilon);
     return vv_launch_status();
 }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     'vv_kl_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'vv_unpack_bits_gather': (_i, [_vp, _vp, _vp, _i, _l, _vp]),
     'vv_pack_bits': (_i, [_vp, _vp, _f, _l, _vp]),
+    'vv_adam_step_multi': (_i, [_vp, _i, _f, _f, _f, _f, _vp]),
     'vv_convert': (_i, [_vp, _vp, _l, _i, _i, _vp]),
     'vv_regulizer_loss': (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),

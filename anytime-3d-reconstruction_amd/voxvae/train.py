@@ -10,6 +10,8 @@ backend 'nccl'; gloo in the CPU tests of the bucketing logic) before Adam runs o
 """
 import ctypes
 
+import numpy as np
+
 import torch
 
 from . import engine as E
@@ -17,6 +19,7 @@ from . import lib as L
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.99          # Keras BatchNormalization defaults
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # tf.keras.optimizers.Adam defaults
+ADAM_CHUNK = 16384                            # elements per record of the vv_adam_step_multi table
 
 
 def _st():
@@ -374,10 +377,18 @@ class Trainer:
         self.grads.all_reduce(self.group)
         self.t += 1
         lr_t = self.lr * (1.0 - ADAM_B2 ** self.t) ** 0.5 / (1.0 - ADAM_B1 ** self.t)
-        for name, _ in self.order:
-            p = self._p(name)
-            L.call('vv_adam_step', L.ptr(p), L.ptr(self._g(name)), L.ptr(self.m[name]), L.ptr(self.v[name]), p.numel(), lr_t,
-                   ADAM_B1, ADAM_B2, ADAM_EPS, st)
+        # one launch for all variables: a device table of <= 16384-element chunks, rebuilt only when a tensor moved
+        ptrs = tuple(self._p(name).data_ptr() for name, _ in self.order)
+        if getattr(self, '_adam_ptrs', None) != ptrs:
+            recs = []
+            for name, _ in self.order:
+                p, g, m, v = self._p(name), self._g(name), self.m[name], self.v[name]
+                for off in range(0, p.numel(), ADAM_CHUNK):
+                    recs.append((p.data_ptr() + 4 * off, g.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off,
+                                 min(ADAM_CHUNK, p.numel() - off)))
+            self._adam_table = torch.from_numpy(np.asarray(recs, dtype=np.int64)).to(self.dev)
+            self._adam_ptrs = ptrs
+        L.call('vv_adam_step_multi', L.ptr(self._adam_table), self._adam_table.shape[0], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS, st)
         if self.enc is not None:
             self.enc._dirty = True
         self.dec._dirty = True

@@ -227,6 +227,11 @@ int vv_reparam_kl_bwd(const float *enc_out, const float *eps, const float *dz, c
 int vv_adam_step(float *param, const float *grad, float *m, float *v, long n, float lr_t, float beta1, float beta2,
                  float epsilon, void *stream);
 
+/* vv_adam_step for every variable in one launch: chunk_table is a device array of nchunks records
+ * { float *param; const float *grad; float *m; float *v; long n; } (40 bytes, pointers already offset, n <= 16384). */
+int vv_adam_step_multi(const void *chunk_table, int nchunks, float lr_t, float beta1, float beta2, float epsilon,
+                       void *stream);
+
 /* dst[i] = (dst type) src[i] between float32 and bf16 (round to nearest even): operand casts of the mixed-precision
  * training step. */
 int vv_convert(const void *src, void *dst, long n, int src_dtype, int dst_dtype, void *stream);
