@@ -47,19 +47,57 @@ class GradBuckets:
             cur_n += n_pad
         if cur:
             plan.append((cur, cur_n))
+        self.bucket_of, self.members = {}, []
         for items, total in plan:
             buf = torch.zeros(total, dtype=torch.float32, device=device)
             self.buckets.append(buf)
+            self.members.append([name for name, _, _, _ in items])
             for name, shape, n, off in items:
                 self.views[name] = buf[off:off + n].view(*shape)
+                self.bucket_of[name] = len(self.buckets) - 1
+        self.begin_step()
+
+    @staticmethod
+    def _distributed(group):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
     def all_reduce(self, group=None):
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-            return
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in self.buckets]
-        for w in works:
-            w.wait()
+        """Sum every bucket across the ranks (blocking form: all launched together, then waited)."""
+        self.begin_step()
+        self.finish(group)
+
+    # -- overlapped form: the backward pass reports gradients as their kernels are enqueued; a bucket's all-reduce is
+    # launched the moment its last member is ready (buckets are laid out in backward order), so the ring transfers of
+    # the decoder's gradients run under the encoder's backward kernels.  With backend 'nccl' (RCCL) the collective runs
+    # on the process group's own stream after an event on the current stream; wait() re-joins it.
+    def begin_step(self):
+        self._pending = [set(m) for m in self.members]
+        self._works = [None] * len(self.buckets)
+        self.launch_order = []
+
+    def ready(self, names, group=None):
+        for name in names:
+            b = self.bucket_of[name]
+            self._pending[b].discard(name)
+            if not self._pending[b] and self._works[b] is None:
+                self._launch(b, group)
+
+    def _launch(self, b, group):
+        self.launch_order.append(b)
+        if self._distributed(group):
+            import torch.distributed as dist
+            self._works[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            self._works[b] = False
+
+    def finish(self, group=None):
+        for b in range(len(self.buckets)):
+            if self._works[b] is None:
+                self._launch(b, group)
+        for w in self._works:
+            if w:
+                w.wait()
 
 
 class _BN:
@@ -85,6 +123,7 @@ class Trainer:
         self.world, self.group = int(world_size), group
         self.t = 0
         self.debug = None          # set to a dict to capture intermediate tensors of the next step (tests)
+        self.overlap = True        # launch each gradient bucket's all-reduce as soon as its last member is enqueued
         self.ws = E._Workspace(self.dev)
         names = [] if enc is None else [('enc/' + k, v.shape) for k, v in enc.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         names += [('dec/' + k, v.shape) for k, v in dec.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
@@ -101,6 +140,10 @@ class Trainer:
 
     def _g(self, name):
         return self.grads.views[name]
+
+    def _ready(self, *names):
+        if self.overlap:
+            self.grads.ready(names, self.group)
 
     def _empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
@@ -136,6 +179,7 @@ class Trainer:
         ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, bn.c))
         L.call('vv_bn_act_bwd', L.ptr(c), L.ptr(dh), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(bn.mean), L.ptr(bn.rstd),
                L.ptr(self._g(gname)), L.ptr(self._g(bname)), L.ptr(dc), rows, bn.c, act, self._dt(c), L.ptr(ws), ws.numel(), _st())
+        self._ready(gname, bname)
         return dc
 
     def _dense(self, x, panel, m, n, k, shift=None, f32_out=False):
@@ -198,6 +242,7 @@ class Trainer:
         """x, y: float32 CUDA [B,D,D,D,1].  Returns device tensors (loss_kl or None, stats [B,4], metrics [4])."""
         self.enc.ensure_packed()
         self.dec.ensure_packed()
+        self.grads.begin_step()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
         enc_out, est = self._encoder_forward(x, B)
@@ -212,9 +257,12 @@ class Trainer:
         caller can continue the backward pass through its own encoder.  l2: coefficient of the decoder's kernel / bias
         regularisers when the caller's loss includes them."""
         self.dec.ensure_packed()
+        self.grads.begin_step()
+        overlap, self.overlap = self.overlap, self.overlap and l2 == 0      # the l2 terms are added before the cross-rank sum
         B = enc_out.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         kl, stats, metrics, de = self._latent_decoder(enc_out, y, eps, drop_mask, drop_scale, B, inv_gb)
+        self.overlap = overlap
         if l2 > 0:      # + sum(decoder.losses) in the total loss (nolbo.py:819-823): d/dw of l2 * sum(w^2)
             for name, _ in self.order:
                 if name.endswith('/kernel') or name == 'dec/dense/bias':
@@ -232,6 +280,7 @@ class Trainer:
             raise ValueError('step_custom_latent expects a Trainer built with variational=False (the decoder input is z_input)')
         self.enc.ensure_packed()
         self.dec.ensure_packed()
+        self.grads.begin_step()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         enc_out, est = self._encoder_forward(x, B)
@@ -308,6 +357,7 @@ class Trainer:
         L.call('vv_bce_bwd', L.ptr(probs), L.ptr(y), L.ptr(dlogit), B, D ** 3, 0.6, 1e-7, inv_gb, st)
         cl = fd[nd - 1]
         self._wgrad_conv(dlogit, dh_[-1], self._g('dec/convT%d/kernel' % nd), B, D, 1, cl)        # [64 taps][cl] = Keras [4,4,4,1,cl]
+        self._ready('dec/convT%d/kernel' % nd)
         w5p = self._aempty(cl, 64)
         L.call('vv_pack_conv_k4', L.ptr(w5), L.ptr(w5p), 1, cl, dt, st)
         dh = self._aempty(B, side, side, side, cl)
@@ -317,6 +367,7 @@ class Trainer:
             dcv = self._bn_bwd(dc_[i], dh, dbn[i], B * side ** 3, 'dec/bnT%d/gamma' % i, 'dec/bnT%d/beta' % i, act)
             wk = dec.params['convT%d/kernel' % i]            # Keras [4,4,4,cout,cin]
             self._wgrad_conv(dcv, dh_[i - 1], self._g('dec/convT%d/kernel' % i), B, side, cout, cin)
+            self._ready('dec/convT%d/kernel' % i)
             dh = self._conv(dcv, wk, B, side, cout, cin)     # read as a forward conv kernel [4,4,4,Cin_c=cout,Cout_c=cin]
             side //= 2
         # D1 (dense panel over the S^3 seed)
@@ -324,6 +375,7 @@ class Trainer:
         dpanel = self._empty(n1, lin)
         self._wgrad_dense(dcv, t0, dpanel, B, n1, lin)
         L.call('vv_unpack_convT_dense_grad', L.ptr(dpanel), L.ptr(self._g('dec/convT0/kernel')), S, ch, fd[0], st)
+        self._ready('dec/convT0/kernel')
         w0f = self._empty(n1, lin)
         L.call('vv_pack_convT_k4s1_dense', L.ptr(dec.params['convT0/kernel']), L.ptr(w0f), S, ch, fd[0], L.VV_F32, st)
         dt0 = self._dense(dcv, self._transposed_panel(w0f, n1, lin), B, lin, n1)
@@ -331,6 +383,7 @@ class Trainer:
         dcv0 = self._bn_bwd(c_d0, dt0, bn_d0, B, 'dec/bn_dense/gamma', 'dec/bn_dense/beta', act)
         L.call('vv_colsum', L.ptr(dcv0), L.ptr(self._g('dec/dense/bias')), B, lin, self._dt(dcv0), st)
         self._wgrad_dense(z_act, dcv0, self._g('dec/dense/kernel'), B, Lz, lin)
+        self._ready('dec/dense/bias', 'dec/dense/kernel')
         dz = self._dense(dcv0, self._cast(dec.params['dense/kernel']), B, Lz, lin, f32_out=True)   # Keras [L][lin] is the [N][K] panel of the data gradient
 
         # ---------------- backward: latent
@@ -355,6 +408,7 @@ class Trainer:
         dpanel = self._empty(E_out, K5)
         self._wgrad_dense(de, eh[-1], dpanel, B, E_out, K5)
         L.call('vv_unpack_meanpool_grad', L.ptr(dpanel), L.ptr(self._g('enc/conv%d/kernel' % ne)), Sside_e, fe[ne - 1], E_out, st)
+        self._ready('enc/conv%d/kernel' % ne)
         wef = self._empty(E_out, K5)
         L.call('vv_pack_conv_k4s1_meanpool', L.ptr(enc.params['conv%d/kernel' % ne]), L.ptr(wef), Sside_e, fe[ne - 1], E_out, L.VV_F32, st)
         dh = self._dense(self._cast(de), self._transposed_panel(wef, E_out, K5), B, K5, E_out)
@@ -364,17 +418,19 @@ class Trainer:
             dcv = self._bn_bwd(ec[i], dh, ebn[i], B * side ** 3, 'enc/bn%d/gamma' % i, 'enc/bn%d/beta' % i, act)
             wk = enc.params['conv%d/kernel' % i]             # Keras [4,4,4,cin,cout]
             self._wgrad_conv(eh[i - 1], dcv, self._g('enc/conv%d/kernel' % i), B, 2 * side, cin, cout)
+            self._ready('enc/conv%d/kernel' % i)
             dh = self._convT(dcv, wk, B, side, cout, cin)    # read as a transposed kernel [4,4,4,Cout_T=cin,Cin_T=cout]
             side *= 2
         dcv = self._bn_bwd(ec[0], dh, ebn[0], B * side ** 3, 'enc/bn0/gamma', 'enc/bn0/beta', act)
         self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0])
+        self._ready('enc/conv0/kernel')
         if self.debug is not None:
             self.debug.update({'h_enc': eh, 'c_enc': ec})
 
     def _apply(self):
         # ---------------- cross-rank gradient sum, then Adam on every replica
         st = _st()
-        self.grads.all_reduce(self.group)
+        self.grads.finish(self.group)
         self.t += 1
         lr_t = self.lr * (1.0 - ADAM_B2 ** self.t) ** 0.5 / (1.0 - ADAM_B1 ** self.t)
         # one launch for all variables: a device table of <= 16384-element chunks, rebuilt only when a tensor moved

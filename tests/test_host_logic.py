@@ -78,6 +78,19 @@ def _bucket_worker(rank, world, port, out):
         gb.views[n].fill_(float(rank + 1) * (i + 1))
     gb.all_reduce()
     ok = all(torch.all(gb.views[n] == float(sum(r + 1 for r in range(world)) * (i + 1))) for i, (n, _) in enumerate(shapes))
+    # overlapped form: a bucket is reduced the moment its last member is reported ready, in backward order
+    for i, (n, s) in enumerate(shapes):
+        gb.views[n].fill_(float(rank + 1) * (i + 1))
+    gb.begin_step()
+    launched = []
+    for n, _ in shapes:
+        gb.ready([n])
+        launched.append(len(gb.launch_order))
+    first_bucket = len(gb.members[0])
+    ok = ok and launched[first_bucket - 2] == 0 and launched[first_bucket - 1] == 1 and gb.launch_order == sorted(gb.launch_order)
+    gb.finish()
+    ok = ok and len(gb.launch_order) == len(gb.buckets)
+    ok = ok and all(torch.all(gb.views[n] == float(sum(r + 1 for r in range(world)) * (i + 1))) for i, (n, _) in enumerate(shapes))
     out[rank] = bool(ok)
     dist.destroy_process_group()
 
