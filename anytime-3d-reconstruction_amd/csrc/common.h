@@ -11,6 +11,34 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((address_space(3))) void *lptr_t;     // LDS pointer (its integer value is the LDS byte address)
+
+// One LDS-DMA instruction (buffer_load_dwordx4 ... lds: 16 B per lane straight into LDS at m0 + lane*16), issued from
+// inline asm ON PURPOSE: hipcc counts its own LDS-DMA builtins as pending LDS writes and puts `s_waitcnt vmcnt(0)` in front
+// of the next ds_read, which serialises the prefetch of chunk k+1 with the MFMAs of chunk k.  The asm form is invisible
+// to that pass; the kernels wait for it by hand (s_waitcnt vmcnt(N) right before the barrier that publishes the buffer).
+// Out-of-range lanes (voff >= num_records) deposit zeros.  m0 is written in the same statement (hipcc does not preserve
+// it); `s_nop 4` covers the SGPR-write -> VMEM-read hazard on m0 / freshly produced descriptor words.
+__device__ __forceinline__ void vv_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ void vv_dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) { vv_dma16(rsrc, voff, 0u, lds_addr); }
+
+// Raw buffer descriptor over [base, base + bytes): the range check is what turns padded taps / tails into zeros.
+__device__ __forceinline__ u32x4 vv_make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);   // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
 
 static inline bool vv_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int vv_log2(int v) {

@@ -24,23 +24,6 @@
 
 namespace {
 
-typedef __attribute__((address_space(3))) void *lptr_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-
-__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
@@ -76,7 +59,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
     const int bd = blk % bxd; const int b = blk / bxd;
     const int od0 = bd * 4, oh0 = bh * 8, ow0 = bw * 8;
 
-    const u32x4 rsx = make_rsrc(x, x_bytes), rsw = make_rsrc(w, w_bytes);
+    const u32x4 rsx = vv_make_rsrc(x, x_bytes), rsw = vv_make_rsrc(w, w_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
     // ---- producers
@@ -89,7 +72,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
         const bool ok = q < 8 && rl < 405 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
         const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * CD_RB + g * 16 : 0xFFFFFFF0u;
         const unsigned dst = piece < CD_PIECES ? lds0 + (q & 1) * CD_TILE + piece * 1024 : lds0 + CD_DUMMY;
-        dma16(rsx, vo, dst);
+        vv_dma16(rsx, vo, dst);
     };
     auto issue_w = [&](int c) {                      // chunk c = q*8 + a into ring[c % 3]: rows 16*wave .. 16*wave+15
         const int q = c >> 3, a = c & 7;
@@ -101,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
             const int row = (wave * 2 + i) * 8 + (lane >> 3);
             const int g = (lane & 7) ^ ((row >> 1) & 7);
             const unsigned vo = c < 64 ? (unsigned)row * (64 * CD_RB) + t * CD_RB + g * 16 : 0xFFFFFFF0u;
-            dma16(rsw, vo, st + (wave * 2 + i) * 1024);
+            vv_dma16(rsw, vo, st + (wave * 2 + i) * 1024);
         }
     };
 

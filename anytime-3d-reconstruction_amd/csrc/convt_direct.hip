@@ -20,23 +20,6 @@
 
 namespace {
 
-typedef __attribute__((address_space(3))) void *lptr_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-
-__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-
 // out[p][a][ks][nt][lane][j] = w[t(p,a)][co = nt*32 + (lane&31)][ci = ks*16 + 8*(lane>>5) + j]
 __global__ void pack_convT_frag_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
     const int KS = cin / 16, NT = cout / 32;
@@ -88,7 +71,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
 
     // ---- stage the halo tile: 360 voxels x 16 slots = 90 wave instructions of 1 KiB (4 voxels each)
     {
-        const u32x4 rs = make_rsrc(x, x_bytes);
+        const u32x4 rs = vv_make_rsrc(x, x_bytes);
         const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)tile;
         const int pos = lane & 15, vsub = lane >> 4;
         for (int it = wave; it < HV / 4; it += 4) {
@@ -98,7 +81,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
             const bool ok = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
             const int g = pos ^ ((zw + 8 * zh) & 15);
             const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * RB + g * 16 : 0xFFFFFFF0u;
-            dma16(rs, vo, lds0 + it * 1024);
+            vv_dma16(rs, vo, lds0 + it * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

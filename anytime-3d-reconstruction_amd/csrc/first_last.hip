@@ -121,12 +121,6 @@ constexpr int FM_PPITCH = 33;           // floats per P row (32 taps of one half
 
 __device__ __forceinline__ int fm_lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-typedef __attribute__((address_space(3))) void *fm_lptr_t;
-typedef __attribute__((ext_vector_type(4))) unsigned fm_u32x4;
-__device__ __forceinline__ void fm_dma16(fm_u32x4 rsrc, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-
 __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                              const float *__restrict__ target, float *__restrict__ probs,
                                                              float *__restrict__ logits, float *__restrict__ partials,
@@ -151,13 +145,8 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
     // stage A by LDS-DMA: 224 rows x 8 slots = 28 wave instructions (8 rows each); rows >= 216 and halo voxels outside
     // the grid come back as zeros (out-of-range buffer offsets)
     {
-        fm_u32x4 rs;
-        const unsigned long long base = reinterpret_cast<unsigned long long>(x);
-        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
-        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
-        rs[2] = __builtin_amdgcn_readfirstlane(x_bytes);
-        rs[3] = 0x00020000u;
-        const unsigned lds0 = (unsigned)(unsigned long long)(fm_lptr_t)As;
+        const u32x4 rs = vv_make_rsrc(x, x_bytes);
+        const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)As;
         const int pos = lane & 7, rsub = lane >> 3;
         for (int it = wv; it < FM_ROWS / 8; it += 4) {
             const int row = it * 8 + rsub;
@@ -166,7 +155,7 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
             const bool ok = row < 216 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
             const int g = pos ^ ((row >> 1) & 7);
             const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
-            fm_dma16(rs, vo, lds0 + it * 1024);
+            vv_dma16(rs, vo, lds0 + it * 1024);
         }
     }
 #pragma unroll
@@ -290,15 +279,8 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
 
-    fm_u32x4 rs;
-    {
-        const unsigned long long base = reinterpret_cast<unsigned long long>(x);
-        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
-        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xFFFFu);
-        rs[2] = __builtin_amdgcn_readfirstlane(x_bytes);
-        rs[3] = 0x00020000u;
-    }
-    const unsigned ldsx = (unsigned)(unsigned long long)(fm_lptr_t)Xs;
+    const u32x4 rs = vv_make_rsrc(x, x_bytes);
+    const unsigned ldsx = (unsigned)(unsigned long long)(lptr_t)Xs;
     // plane d -> ring slot d % 3: 13 pieces of 8 rows; every wave issues 4 (the 3 surplus ones go to the sink so that the
     // vector-memory counter advances uniformly); rows >= 100, voxels outside the grid and planes outside [0, n) arrive
     // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
@@ -312,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
             const int g = (lane & 7) ^ ((row >> 1) & 7);
             const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
-            fm_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
+            vv_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
         }
     };
     stage(0);

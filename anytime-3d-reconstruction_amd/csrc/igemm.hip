@@ -182,32 +182,6 @@ __device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, 
     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc, 0, 0, 0);
 }
 
-typedef __attribute__((address_space(3))) void *lptr_t;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-// One LDS-DMA instruction (buffer_load_dwordx4 ... lds: 16 B per lane straight into LDS at m0 + lane*16), issued from
-// inline asm ON PURPOSE: hipcc counts its own LDS-DMA builtins as pending LDS writes and puts `s_waitcnt vmcnt(0)` in front
-// of the next ds_read, which serialises the prefetch of chunk k+1 with the MFMAs of chunk k.  The asm form is invisible
-// to that pass; the kernel waits for it by hand (vmcnt(0) right before the barrier that publishes the buffer).
-// Out-of-range lanes (voff >= num_records) deposit zeros.  m0 is written in the same statement (hipcc does not preserve
-// it); `s_nop 4` covers the SGPR-write -> VMEM-descriptor-read hazard for freshly produced descriptor words.
-__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
-}
-
-__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);   // stride 0: raw buffer
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-
 template <typename T, int MODE, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int BK = Elt<T>::BK;
@@ -254,7 +228,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // LDS-DMA goes through buffer descriptors: a lane whose offset is out of range deposits ZEROS in its LDS slot, which
     // is exactly what a tap in the SAME padding (or a row past M / N / K) must contribute -- no zero page, no branches.
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    const u32x4 rsA = make_rsrc(a.A, a.a_bytes), rsW = make_rsrc(a.W, a.w_bytes);
+    const u32x4 rsA = vv_make_rsrc(a.A, a.a_bytes), rsW = vv_make_rsrc(a.W, a.w_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the staging area
     int aoff[RA];                     // byte offset of (row, tap 0, channel 0, this lane's slot); garbage where never valid
     unsigned long long rmask[RA];     // per-tap validity of the row
@@ -314,12 +288,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             if constexpr (MODE == MODE_CONV) v = (rmask[i] >> tap) & 1ull;
             else v = ((unsigned)rmask[i] >> tap) & 1u;
             const unsigned vo = (v && kin) ? (unsigned)(aoff[i] + delta) : OOB;
-            dma16(rsA, vo, 0u, lds0 + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB);
+            vv_dma16(rsA, vo, 0u, lds0 + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const unsigned vo = kin ? woff[i] : OOB;
-            dma16(rsW, vo, (unsigned)(kc * ROWB), lds0 + STAGES * BM * ROWB + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB);
+            vv_dma16(rsW, vo, (unsigned)(kc * ROWB), lds0 + STAGES * BM * ROWB + buf * BN * ROWB + (wave * 8 + 32 * i) * ROWB);
         }
     };
 

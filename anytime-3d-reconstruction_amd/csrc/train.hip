@@ -314,23 +314,6 @@ struct WgradBArgs {
     unsigned a_bytes, g_bytes;
 };
 
-typedef __attribute__((address_space(3))) void *wg_lptr_t;
-typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned wg_u32x2;
-
-__device__ __forceinline__ void wg_dma16(wg_u32x4 rsrc, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ wg_u32x4 wg_rsrc(const void *base, unsigned bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    wg_u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xFFFFu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-
 template <int AMODE>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) {
     constexpr int BM = 128, BN = 128, BR = 64, OPB = BR * 128 * 2;        // one operand chunk: 16 KiB
@@ -344,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     const long r_begin = (long)blockIdx.y * a.rows_per_split;
     const long r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
     const int li = a.din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
-    const wg_u32x4 rsa = wg_rsrc(a.A, a.a_bytes), rsg = wg_rsrc(a.G, a.g_bytes);
-    const unsigned lds0 = (unsigned)(unsigned long long)(wg_lptr_t)smem;
+    const u32x4 rsa = vv_make_rsrc(a.A, a.a_bytes), rsg = vv_make_rsrc(a.G, a.g_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
     // staging: piece = (column block cb, 16-row group rg): 16 rows x 64 B; 16 pieces per operand, 4 per wave each
     const int prow = lane >> 2, pch = lane & 3;
@@ -372,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
                 if (ncol < a.N) vg = (unsigned)((r * a.N + ncol + pch * 8) * 2);
             }
             const unsigned dst = lds0 + st * (2 * OPB) + cb * 4096 + rg * 1024;
-            wg_dma16(rsa, va, dst);
-            wg_dma16(rsg, vg, dst + OPB);
+            vv_dma16(rsa, va, dst);
+            vv_dma16(rsg, vg, dst + OPB);
         }
     };
 
@@ -389,10 +372,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const unsigned troff = ((g4 >> 1) * 8 + q4) * 64 + ((g4 & 1) * 16 + p4 * 4) * 2;
     auto frag = [&](unsigned base) -> bf16x8 {       // base = operand + column block + k-step: rows +0..3 then +4..7
-        wg_u32x2 lo2, hi2;
+        u32x2 lo2, hi2;
         asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(lo2), "=&v"(hi2) : "v"(base + troff) : "memory");
-        wg_u32x4 v = {lo2[0], lo2[1], hi2[0], hi2[1]};
+        u32x4 v = {lo2[0], lo2[1], hi2[0], hi2[1]};
         return *reinterpret_cast<bf16x8 *>(&v);
     };
 
