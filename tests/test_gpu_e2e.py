@@ -151,3 +151,24 @@ def test_full_batch_256_properties_bf16():
     iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64)).mean()
     print('\n[B256 bf16] IoU gpu %.6f cpu %.6f' % (iou_g, iou_c))
     assert abs(iou_g - iou_c) <= 1e-3
+
+
+@pytest.mark.parametrize('D,B', [(16, 1), (16, 33), (32, 1), (32, 3), (32, 33), (32, 45), (32, 100), (64, 5)])
+def test_ragged_batches_bf16_against_c_oracle(D, B):
+    """Ragged batch sizes across the kernel-selection thresholds (direct / implicit-GEMM layers, plane / gather first layer,
+    sweep / box last layer, position-major rows, XCD remap on grids that are not multiples of 8): per-sample losses and
+    counts against the C oracle."""
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(D, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x = syn.make_voxels(B, D, seed=1000 + B)
+    eps = syn.make_eps(B, 64, seed=B)
+    r = _run(cfg, ep, dp, x, x, eps, 'bf16')
+    c = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
+    s = r['stats'].astype(np.float64)
+    iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3])
+    iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64))
+    assert np.abs(iou_g - iou_c).max() <= 5e-3 and abs(iou_g.mean() - iou_c.mean()) <= 1e-3
+    np.testing.assert_allclose(s[:, 0], c['bce'], rtol=2e-2)
+    assert np.abs(r['logits'] - c['logits']).max() < 0.05 * max(1.0, np.abs(c['logits']).max())
