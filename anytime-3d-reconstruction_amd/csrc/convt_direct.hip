@@ -9,8 +9,10 @@
 //
 //   LDS tile   : 360 voxels x CIN bf16, 16-byte slots XOR-swizzled with (zw + 8 zh) & 15 -- conflict-free for every
 //                tap and both ds_read_b128 lane groups (exhaustively checked offline)
-//   waves      : 4; wave w owns parities 2w, 2w+1 (one after the other): 4 row tiles (md = 0..3, 32 cells each)
-//                x COUT/32 channel tiles of 32x32 accumulators; weights-first MFMA, lane = cell, registers walk channels
+//   waves      : default 8 (one output parity each) over a 4 x 4 x 8 block of cells: 4 row tiles (32 cells each) x COUT/32
+//                channel tiles of 32x32 accumulators per wave, so every streamed weight fragment feeds 4 MFMAs; the 4-wave
+//                forms (2 parities per wave, 2 x 4 x 8 or 4 x 4 x 8 cells) remain selectable (VV_DIRECT_MT = 2 / 4);
+//                weights-first MFMA, lane = cell, registers walk channels
 //   epilogue   : folded BN + activation on float4 quads, wave-private LDS transpose, 16-byte stores of whole channel rows
 #include <stdlib.h>
 
@@ -41,15 +43,15 @@ __global__ void pack_convT_frag_kernel(const float *__restrict__ w, __bf16 *__re
 
 constexpr int HH = 6, HW = 10;   // halo tile of an MT x 4 x 8 block of cells: (MT+2) x 6 x 10 voxels
 
-template <int CIN, int COUT, int MT>
-__global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wf,
+template <int CIN, int COUT, int MT, int NW>      // NW waves per workgroup; a wave owns 8 / NW output parities
+__global__ __launch_bounds__(NW * 64, (NW == 8 || MT == 4) ? 1 : 2) void convT_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ wf,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
                                                               __bf16 *__restrict__ y, int din_log2, unsigned x_bytes, int act) {
     constexpr int RB = CIN * 2;          // bytes per voxel row
     constexpr int SPR = RB / 16;         // 16-byte slots per row (16 for CIN = 128)
     constexpr int KS = CIN / 16;         // MFMA k-steps per tap
     constexpr int NT = COUT / 32;        // channel tiles
-    constexpr int HALF = 2;              // k-steps per weight prefetch group (4 groups in the ring = 64 VGPRs)
+    constexpr int HALF = (MT == 4 && NW == 8) ? 1 : 2;   // k-steps per weight prefetch group (4 groups in the register ring)
     constexpr int GPT = KS / HALF;       // groups per tap
     constexpr int GPP = 8 * GPT;         // groups per parity
     constexpr int SPITCH = COUT * 2 + 16;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
         const u32x4 rs = vv_make_rsrc(x, x_bytes);
         const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)tile;
         const int pos = lane & 15, vsub = lane >> 4;
-        for (int it = wave; it < HV / 4; it += 4) {
+        for (int it = wave; it < HV / 4; it += NW) {
             const int v = it * 4 + vsub;
             const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
             const int id = d0 - 1 + zd, ih = h0 - 1 + zh, iw = w0 - 1 + zw;
@@ -97,10 +99,11 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
     // streamed through a 4-deep register ring (3 groups = 96 MFMAs ~ 3 k cycles of prefetch distance: with one wave per
     // SIMD nothing else hides the L2 latency), running ahead across the parity boundary and its epilogue.
     constexpr int GL = HALF * NT;                          // 16-byte loads per lane per group
-    const uint4 *wp = wfl + (size_t)(wave * 2 * GPP) * GL * 64;
+    constexpr int PPW = 8 / NW;                            // parities per wave
+    const uint4 *wp = wfl + (size_t)(wave * PPW * GPP) * GL * 64;
     uint4 b0[GL], b1[GL], b2[GL], b3[GL];
     auto load_group = [&](int G, uint4 *dst) {
-        if (G < 2 * GPP) {
+        if (G < PPW * GPP) {
             const uint4 *src = wp + (size_t)G * GL * 64;
 #pragma unroll
             for (int i = 0; i < GL; ++i) dst[i] = src[(size_t)i * 64];
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
 
     auto run_parity = [&](auto act_c, int pi) {
         constexpr int ACT = decltype(act_c)::value;
-        const int p = wave * 2 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        const int p = wave * PPW + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
         f32x16 acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -155,20 +158,31 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
             __builtin_amdgcn_sched_barrier(0);
         };
         // one group = HALF k-steps of one tap with the weights of ring buffer bf; k-steps alternate P, Q (HALF is even)
-        static_assert(HALF % 2 == 0, "P/Q roles must line up across groups");
+        constexpr bool PINGPONG = !(MT == 4 && NW == 8);    // the 8-wave form has no registers left for a second set
+        static_assert(!PINGPONG || HALF % 2 == 0, "P/Q roles must line up across groups");
         auto compute_group = [&](int g, const uint4 *bf) {
             const int a = g / GPT, part = g % GPT;
+            if constexpr (PINGPONG) {
 #pragma unroll
-            for (int k = 0; k < HALF; k += 2) {
-                const int ks = part * HALF + k;
-                ld(fQ, a_addr(a, ks + 1));
-                wait(fP);
-                mma(fP, bf + k * NT);
-                // the k-step after next: same tap, or the first of the next tap (wraps harmlessly after the last one)
-                const int ks2 = ks + 2;
-                ld(fP, ks2 < KS ? a_addr(a, ks2) : a_addr((a + 1) & 7, 0));
-                wait(fQ);
-                mma(fQ, bf + (k + 1) * NT);
+                for (int k = 0; k < HALF; k += 2) {
+                    const int ks = part * HALF + k;
+                    ld(fQ, a_addr(a, ks + 1));
+                    wait(fP);
+                    mma(fP, bf + k * NT);
+                    // the k-step after next: same tap, or the first of the next tap (wraps harmlessly after the last one)
+                    const int ks2 = ks + 2;
+                    ld(fP, ks2 < KS ? a_addr(a, ks2) : a_addr((a + 1) & 7, 0));
+                    wait(fQ);
+                    mma(fQ, bf + (k + 1) * NT);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < HALF; ++k) {
+                    const int ks = part * HALF + k;
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fP[0]), "+v"(fP[1]), "+v"(fP[MT - 2]), "+v"(fP[MT - 1]) : : "memory");
+                    mma(fP, bf + k * NT);
+                    ld(fP, ks + 1 < KS ? a_addr(a, ks + 1) : a_addr((a + 1) & 7, 0));
+                }
             }
         };
         ld(fP, a_addr(0, 0));
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 1 : 2) void convT_direct_kernel(cons
         }
     };
 #pragma unroll 1
-    for (int pi = 0; pi < 2; ++pi) {
+    for (int pi = 0; pi < PPW; ++pi) {
         switch (act) {
             case VV_ACT_ELU: run_parity(std::integral_constant<int, VV_ACT_ELU>{}, pi); break;
             case VV_ACT_RELU: run_parity(std::integral_constant<int, VV_ACT_RELU>{}, pi); break;
@@ -274,30 +288,26 @@ VV_EXPORT int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, cons
     if (!vv_aligned16(x) || !vv_aligned16(w_frag) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const size_t xb = (size_t)batch * side * side * side * cin * 2;
     if (xb >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
-    static const int mt_sel = getenv("VV_DIRECT_MT") ? atoi(getenv("VV_DIRECT_MT")) : 2;
+    // variants: "2" = 2x4x8 cells, 4 waves x 2 parities, 2 workgroups / CU; "4" = 4x4x8 cells, 4 waves x 2 parities;
+    // "8" = 4x4x8 cells, 8 waves x 1 parity (each weight fragment feeds 4 MFMAs, 2 waves / SIMD)
+    const char *sel_env = getenv("VV_DIRECT_MT");                       // read per call so that tests can cover every variant
+    const int sel = sel_env ? atoi(sel_env) : 8;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (mt_sel == 4) {
-        const int boxes = (side / 4) * (side / 4) * (side / 8);
-        const size_t lds = (size_t)6 * HH * HW * cin * 2 + 4 * 32 * (cout * 2 + 16);
+    auto launch = [&](auto mt_c, auto nw_c) {
+        constexpr int MT = decltype(mt_c)::value, NW = decltype(nw_c)::value;
+        const int boxes = (side / MT) * (side / 4) * (side / 8);
+        constexpr int LDS = (MT + 2) * HH * HW * 128 * 2 + NW * 32 * (64 * 2 + 16);
         static const bool attr = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_kernel<128, 64, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 6 * HH * HW * 128 * 2 + 4 * 32 * (64 * 2 + 16));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_kernel<128, 64, MT, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             return true;
         }();
         (void)attr;
-        VV_LAUNCH((convT_direct_kernel<128, 64, 4>), dim3(batch * boxes), dim3(256), lds, st, reinterpret_cast<const __bf16 *>(x),
+        VV_LAUNCH((convT_direct_kernel<128, 64, MT, NW>), dim3(batch * boxes), dim3(NW * 64), LDS, st, reinterpret_cast<const __bf16 *>(x),
                   reinterpret_cast<const __bf16 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y), vv_log2(side), (unsigned)xb, act);
-    } else {
-        const int boxes = (side / 2) * (side / 4) * (side / 8);
-        const size_t lds = (size_t)4 * HH * HW * cin * 2 + 4 * 32 * (cout * 2 + 16);
-        static const bool attr = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_kernel<128, 64, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HH * HW * 128 * 2 + 4 * 32 * (64 * 2 + 16));
-            return true;
-        }();
-        (void)attr;
-        VV_LAUNCH((convT_direct_kernel<128, 64, 2>), dim3(batch * boxes), dim3(256), lds, st, reinterpret_cast<const __bf16 *>(x),
-                  reinterpret_cast<const __bf16 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y), vv_log2(side), (unsigned)xb, act);
-    }
+    };
+    if (sel == 8) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
+    else if (sel == 4) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+    else launch(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
     return vv_launch_status();
 }

@@ -238,9 +238,12 @@ def test_error_codes(L):
         L.call('vv_shape_metrics', None, None, 1, None)
 
 
+@pytest.mark.parametrize('variant', ['8', '4', '2'])
 @pytest.mark.parametrize('B,side', [(2, 8), (1, 16), (3, 8)])
-def test_convT3d_k4s2_direct(L, B, side):
-    """LDS-resident input-tile variant of the widest decoder layer (bf16, 128 -> 64)."""
+def test_convT3d_k4s2_direct(L, B, side, variant, monkeypatch):
+    """LDS-resident input-tile variant of the widest decoder layer (bf16, 128 -> 64): 8 waves x 1 parity (default), and the
+    two 4-wave x 2-parity forms."""
+    monkeypatch.setenv('VV_DIRECT_MT', variant)
     cin, cout = 128, 64
     assert L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, L.VV_BF16) == 1
     assert L.load().vv_convT3d_k4s2_direct_supported(4, cin, cout, L.VV_BF16) == 0
