@@ -125,7 +125,7 @@ def main():
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:       # under torch.distributed.run (also with one rank: same code path as N > 1)
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device(dev))   # RCCL on ROCm
 
