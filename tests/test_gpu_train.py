@@ -1,5 +1,7 @@
 """GPU parity of one training step (fit) against the torch-CPU float64 autograd oracle: losses, every gradient,
 the Adam-updated weights and the BatchNorm moving statistics.  f32 (exact-f32 MFMA) mode."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -164,3 +166,52 @@ def test_bf16_mixed_precision_fit_tracks_the_oracle(D, Lz, var, B):
     for _ in range(4):
         out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
     assert float(out[1 if var else 0]) < l0
+
+
+def _dp_worker(rank, world, port, shards, eps_shards, out):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from voxvae import train as T
+    cfg, ep, dp, model, _, _ = _setup(32, 64, True, 2)
+    tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-3, world_size=world)
+    x = torch.from_numpy(shards[rank]).to(DEV)
+    tr.step(x, x, torch.from_numpy(eps_shards[rank]).to(DEV))
+    torch.cuda.synchronize()
+    out[rank] = {n: tr.grads.views[n].cpu().numpy().copy() for n, _ in tr.order}
+    out['w%d' % rank] = model._encoder.get_weights_dict()['conv1/kernel'].copy()
+    out['launch%d' % rank] = list(tr.grads.launch_order)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks():
+    """BASELINE config 4 semantics (AE3D.py:46-48, 86-104) with two real processes sharing the GPU (gloo): per-rank loss
+    scaled by the GLOBAL batch, per-rank BatchNorm statistics, gradient buckets summed across ranks while the backward is
+    still running, Adam on every replica.  Both ranks must end with the sum of the two shard gradients and identical weights."""
+    import torch.multiprocessing as mp
+    from voxvae import train as T
+    from voxvae import synthetic as syn
+    world = 2
+    shards = [syn.make_voxels(3, 32, seed=900 + r) for r in range(world)]
+    eps_shards = [syn.make_eps(3, 64, seed=950 + r) for r in range(world)]
+    expect = None
+    for r in range(world):                                   # single process: each shard's gradient with the global-batch scaling
+        cfg, ep, dp, model, _, _ = _setup(32, 64, True, 2)
+        tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-3, world_size=world)
+        x = torch.from_numpy(shards[r]).to(DEV)
+        tr.step(x, x, torch.from_numpy(eps_shards[r]).to(DEV))
+        g = {n: tr.grads.views[n].cpu().numpy().astype(np.float64) for n, _ in tr.order}
+        expect = g if expect is None else {n: expect[n] + g[n] for n in g}
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(world, port, shards, eps_shards, out), nprocs=world, join=True)
+    for n, e in expect.items():
+        for r in range(world):
+            got = out[r][n].astype(np.float64)
+            assert np.abs(got - e).max() <= 1e-6 * np.abs(e).max() + 1e-12, (n, r)
+        np.testing.assert_array_equal(out[0][n], out[1][n])
+    np.testing.assert_array_equal(out['w0'], out['w1'])
+    assert out['launch0'] == sorted(out['launch0']) and len(out['launch0']) >= 1
