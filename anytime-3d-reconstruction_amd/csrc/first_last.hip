@@ -323,24 +323,9 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
     int oldh = 0;
 
-#pragma unroll 1
-    for (int d = 0; d <= n; ++d) {
-        const int od = 2 * d - 1 + sl;
-        const bool ovalid = (unsigned)od < (unsigned)n2;
-        const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
-        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
-        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
-        // plane d+1 issued right after it -- the look-ahead.  In flight, oldest first:
-        //   [plane d x4][stores d-1] [y d][plane d+1 x4]
-        // so "all but the newest 5" covers plane d whatever the number of stores (more stores only wait for more).
-        float2 y;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
-        stage(d + 1);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d (issued a step ago) has landed
-        __syncthreads();                                         // ... for every wave; previous gather finished
-
+    // P_d = X_d W^T for this wave's two row tiles and its tap half: D[tap][cell], weights-first
+    auto mfma_plane = [&](int d, f32x16 (&acc)[2]) {
         const char *Xd = Xs + (d % SW_NX) * SW_XB;
-        f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -350,9 +335,22 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 fa = *reinterpret_cast<const uint4 *>(Xd + fm_lds_off(mt * 32 + fr, ks * 2 + fh));
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
-                                                                 *reinterpret_cast<const bf16x8 *>(&fa), acc[j], 0, 0, 0);   // D[tap][cell]
+                                                                 *reinterpret_cast<const bf16x8 *>(&fa), acc[j], 0, 0, 0);
             }
         }
+    };
+
+    // Software pipeline: step d publishes P_d (computed during step d-1) and then runs the MFMAs of plane d+1 in the same
+    // instruction stream as the gather / loss math of plane d (matrix pipe under the VALU and LDS work).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // plane 0
+    __syncthreads();                                             // ... and the zeroed P_{-1}, for every wave
+    f32x16 acc[2];
+    mfma_plane(0, acc);
+    stage(1);
+    __syncthreads();                                             // slot 0 may be refilled (plane 2) from the first step on
+
+#pragma unroll 1
+    for (int d = 0; d <= n; ++d) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
         // of one (td, th): one 16-byte store per quad
         float *Pw = nt == 0 ? PL : PH + (oldh ^ 1) * SW_PSZ;
@@ -366,7 +364,22 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
                         f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
             }
         }
-        __syncthreads();
+        const int od = 2 * d - 1 + sl;
+        const bool ovalid = (unsigned)od < (unsigned)n2;
+        const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
+        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
+        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
+        // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
+        //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
+        // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
+        float2 y;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
+        stage(d + 2);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d+1 (issued a step ago) has landed
+        __syncthreads();                                         // ... for every wave; P_d is published
+
+        f32x16 acc_next[2];
+        mfma_plane(d + 1, acc_next);
 
         float l0 = 0.f, l1 = 0.f;
         const float *Pold = PH + oldh * SW_PSZ;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             l0 += r0[SW_PP + 1] + r0[3] + r1[SW_PP + 1] + r1[3];                         // pw = 0
             l1 += r0[2 * SW_PP] + r0[SW_PP + 2] + r1[2 * SW_PP] + r1[SW_PP + 2];   // pw = 1
         }
-        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+1 may still be in flight
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
         if (ovalid) {
             const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
             float p[2];
@@ -393,7 +406,10 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
             if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
         }
+        acc[0] = acc_next[0];
+        acc[1] = acc_next[1];
         oldh ^= 1;
+        __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
     bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
