@@ -45,3 +45,86 @@ def parse(description, train=False):
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--device-data', action='store_true', help='keep the split in HBM as packed bits (deviceDataLoader)')
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Shared loop plumbing of the train_* / test_* entry points.  The reference scripts each carry their own copy of the
+# same bookkeeping (running means reset at epoch boundaries, one status line rewritten in place, a NaN stop); here it
+# lives once.  The printed fields and their order are those of the reference scripts.
+import sys
+import time
+
+import numpy as np
+
+
+class RunningMeans:
+    """Per-epoch running means of several result tuples (the `loss = (loss * it + new) / (it + 1)` idiom)."""
+
+    def __init__(self, **widths):
+        self.n = 0
+        self.sums = {k: np.zeros(w) for k, w in widths.items()}
+
+    def reset(self):
+        self.n = 0
+        for v in self.sums.values():
+            v[:] = 0
+
+    def add(self, **values):
+        for k, v in values.items():
+            self.sums[k] += np.array([float(x) for x in v])
+        self.n += 1
+
+    def __getitem__(self, key):
+        return self.sums[key] / max(self.n, 1)
+
+    def finite(self):
+        return all(np.all(np.isfinite(v)) for v in self.sums.values())
+
+
+class Progress:
+    """One carriage-return status line: iteration, mean step time, epoch, loader position, then labelled groups."""
+
+    def __init__(self, width=4):
+        self.pos_fmt = "cur_o/tot_o:{:0%dd}/{:0%dd} " % (width, width)
+        self.elapsed, self.n = 0.0, 0
+        self._t0 = None
+
+    def reset(self):
+        self.elapsed, self.n = 0.0, 0
+
+    def tic(self):
+        self._t0 = time.time()
+
+    def toc(self):
+        self.elapsed += time.time() - self._t0
+        self.n += 1
+
+    @staticmethod
+    def group(pairs, sep=", "):
+        return sep.join("%s:%.4f" % (k, v) for k, v in pairs)
+
+    def show(self, epoch, position, total, *groups):
+        head = "it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(self.n, self.elapsed / max(self.n, 1), int(epoch) + 1)
+        sys.stdout.write(head + self.pos_fmt.format(position, total) + " ".join(groups) + "  \r")
+        sys.stdout.flush()
+
+
+def epochs_of(loader, limit, position_attr, on_new_epoch=None):
+    """Yields (epoch, position, total) before every batch until `limit` epochs have been served; calls `on_new_epoch()`
+    when the loader's epoch counter has advanced (the scripts save the model and restart their running means there)."""
+    epoch, first = loader.epoch, True
+    while loader.epoch < limit:
+        if loader.epoch != epoch and not first:
+            epoch = loader.epoch
+            if on_new_epoch is not None:
+                on_new_epoch()
+        first = False
+        yield loader.epoch, getattr(loader, position_attr), loader.dataLength
+
+
+def stop_on_nan(means):
+    if means.finite():
+        return False
+    print('')
+    print('NaN')
+    return True

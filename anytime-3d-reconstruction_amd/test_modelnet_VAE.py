@@ -1,15 +1,38 @@
-"""Entry point mirroring the reference's test_modelnet_VAE.py (loop :104-156, printed fields :141-150, config
+"""Entry point with the role of the reference's test_modelnet_VAE.py (loop :104-156, printed fields :141-150, config
 :169-192): one epoch of getEval over the test split with missing-latent correction.
-`python test_modelnet_VAE.py --voxel 32 --batch 256 --dtype bf16 --missing-pr 0.9`."""
+`python test_modelnet_VAE.py --voxel 32 --batch 256 --dtype bf16 --missing-pr 0.9 [--device-data]`."""
 import os
 import sys
-import time
 
 import numpy as np
 
 import _entry_common as C
 import voxvae
 from src.dataset_loader.modelnet_dataset import dataLoader, deviceDataLoader
+
+FIELDS = ('loss', 'pr', 'rc', 'c'), ('closs', 'cpr', 'crc', 'cc')
+
+
+def evaluate(model, loader, missing_pr, batch_size, max_iter, class_key='class_list', **extra):
+    """The shared test loop: getEval over one epoch, running means of the 8 reported numbers."""
+    means = C.RunningMeans(eval=8)
+    bar = C.Progress(width=5)
+    print('start training...')
+    for epoch, position, total in C.epochs_of(loader, 1, 'batchStart'):
+        bar.tic()
+        batch = loader.getNextBatch(batchSize=batch_size)
+        x = batch['input_images']
+        out = model.getEval(inputs=(x, x, batch[class_key]), missing_prob=missing_pr, **extra)
+        means.add(eval=out[1:5] + out[6:10])
+        bar.toc()
+        m = means['eval']
+        bar.show(epoch, position, total, bar.group(zip(FIELDS[0], m[:4])) + ",", bar.group(zip(FIELDS[1], m[4:])))
+        if C.stop_on_nan(means):
+            return None
+        if max_iter is not None and means.n >= max_iter:
+            break
+    print('')
+    return means['eval']
 
 
 def train(
@@ -25,70 +48,19 @@ def train(
     model = cls(nolbo_structure=config, learning_rate=learning_rate)
     voxel = config['encoder']['input_shape'][0]
     # device_data: the split stays in HBM as packed bits and batches are gathered + unpacked on the GPU (no per-iteration copy)
-    data_loader_test = (deviceDataLoader if device_data else dataLoader)(data_path=dataset_path, trainortest='test', voxel=voxel)
-
+    loader = (deviceDataLoader if device_data else dataLoader)(data_path=dataset_path, trainortest='test', voxel=voxel)
     category_vectors = None
-    if load_path != None:
+    if load_path is not None:
         print('load weights...')
         model.loadModel(load_path=load_path)
         print('done!')
         cv = os.path.join(load_path, 'category_vectors.npy')
         if os.path.exists(cv):
-            category_vectors = np.load(cv).astype('float32')     # reference :123 (re-read every iteration there)
+            category_vectors = np.load(cv).astype('float32')     # the reference re-reads this file every iteration (:123)
     if category_vectors is None:                                  # no prototypes on disk: seeded stand-ins
         from voxvae import synthetic as syn
         category_vectors = syn.make_category_vectors(40, config['z_category_dim'])
-
-    loss = np.zeros(8)
-    epoch, epoch_curr = 0., 0.
-    iteration, run_time = 0., 0.
-
-    print('start training...')
-    while epoch < 1:
-        start_time = time.time()
-        epoch_curr = data_loader_test.epoch
-        data_start = data_loader_test.batchStart
-        data_length = data_loader_test.dataLength
-
-        batch_data = data_loader_test.getNextBatch(batchSize=batch_size)
-        category_list, input_images, output_images = batch_data['class_list'], batch_data['input_images'], batch_data['input_images']
-        inputs = input_images, output_images, category_list
-
-        if epoch != epoch_curr and iteration != 0:
-            break
-        epoch = epoch_curr
-
-        output_images_pred, loss_shape, pr, rc, acc_cat, \
-            output_images_pred_corrected, loss_shape_corrected, pr_corrected, rc_corrected, acc_cat_corrected = model.getEval(
-                inputs=inputs, category_vectors=category_vectors, missing_prob=missing_pr)
-
-        loss_temp = loss_shape, pr, rc, acc_cat, loss_shape_corrected, pr_corrected, rc_corrected, acc_cat_corrected
-        loss_temp = [float(v) for v in loss_temp]
-        end_time = time.time()
-
-        loss = (loss * iteration + np.array(loss_temp)) / (iteration + 1.0)
-        run_time = (run_time * iteration + (end_time - start_time)) / (iteration + 1.0)
-
-        sys.stdout.write(
-            "it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(int(iteration + 1), run_time, int(epoch + 1)))
-        sys.stdout.write("cur_o/tot_o:{:05d}/{:05d} ".format(data_start, data_length))
-        sys.stdout.write(
-            "loss:{:.4f}, pr:{:.4f}, rc:{:.4f}, c:{:.4f}, ".format(
-                loss[0], loss[1], loss[2], loss[3]))
-        sys.stdout.write(
-            "closs:{:.4f}, cpr:{:.4f}, crc:{:.4f}, cc:{:.4f}  \r".format(
-                loss[4], loss[5], loss[6], loss[7]))
-        sys.stdout.flush()
-
-        if np.sum(loss) != np.sum(loss):
-            print('')
-            print('NaN')
-            return
-        iteration += 1.0
-        if max_iter is not None and iteration >= max_iter:
-            break
-    print('')
-    return loss
+    return evaluate(model, loader, missing_pr, batch_size, max_iter, category_vectors=category_vectors)
 
 
 latent_dim = 64

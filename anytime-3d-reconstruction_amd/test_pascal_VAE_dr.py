@@ -4,7 +4,6 @@ latent 16, 64^3 decoder, missing-latent correction against the class prototypes.
 `python test_pascal_VAE_dr.py --batch 16 --image 128 --missing-pr 0.9 --max-iter 2`."""
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -23,6 +22,21 @@ def make_config(latent_dim=16, voxel=64):
     }
 
 
+class _PascalBatches:
+    """Adapts the Pascal loader (positional tuple, `dataStart`) to the dict / `batchStart` interface of the shared loop."""
+
+    def __init__(self, loader, image_size):
+        self._l, self._size = loader, image_size
+
+    epoch = property(lambda self: self._l.epoch)
+    batchStart = property(lambda self: self._l.dataStart)
+    dataLength = property(lambda self: self._l.dataLength)
+
+    def getNextBatch(self, batchSize):
+        _, classes, _, _, images, voxels = self._l.getNextBatch(batchSizeof3DShape=batchSize, imageSize=self._size, augmentation=False)
+        return {'input_images': images, 'output_images': voxels, 'class_list': classes}
+
+
 def train(
         learning_rate=1e-4,
         config=None,
@@ -35,61 +49,42 @@ def train(
     import src.module.nolbo as nolbo
     model = nolbo.nolboSingleObject_VAE(nolbo_structure=config, backbone_style=Darknet.Darknet19, learning_rate=learning_rate)
     voxel = config['decoder']['output_shape'][0]
-    data_loader_pascal = pascal3D.dataLoaderSingleObject(trainOrVal='val', Pascal3DDataPath=dataset_path, voxel=voxel)
-
+    loader = _PascalBatches(pascal3D.dataLoaderSingleObject(trainOrVal='val', Pascal3DDataPath=dataset_path, voxel=voxel), image_size)
     category_vectors = None
-    if load_path != None:
+    if load_path is not None:
         print('load weights...')
         model.loadModel(load_path=load_path)
         print('done!')
         cv = os.path.join(load_path, 'category_vectors.npy')
         if os.path.exists(cv):
             category_vectors = np.load(cv).astype('float32')
-    if load_encoder_backbone_path != None:
+    if load_encoder_backbone_path is not None:
         model.loadEncoderBackbone(load_path=load_encoder_backbone_path, file_name=load_encoder_backbone_name)
-    if load_decoder_path != None:
+    if load_decoder_path is not None:
         model.loadDecoder(load_path=load_decoder_path, file_name=load_decoder_name)
     if category_vectors is None:
         from voxvae import synthetic as syn
         category_vectors = syn.make_category_vectors(pascal3D.CLASSES, config['encoder_backbone']['z_dim'])
 
-    loss = np.zeros(8)
-    epoch, epoch_curr = 0., 0.
-    iteration, run_time = 0., 0.
+    means = C.RunningMeans(eval=8)
+    bar = C.Progress(width=5)
     print('start training...')
-    while epoch < 1:
-        start_time = time.time()
-        epoch_curr = data_loader_pascal.epoch
-        data_start = data_loader_pascal.dataStart
-        data_length = data_loader_pascal.dataLength
-        batch_data = data_loader_pascal.getNextBatch(batchSizeof3DShape=batch_size, imageSize=image_size, augmentation=False)
-        inst_list, category_list, sin, cos, input_images, output_images = batch_data
-        inputs = input_images, output_images, category_list
-        if epoch != epoch_curr and iteration != 0:
-            break
-        epoch = epoch_curr
-
-        output_images_pred, loss_shape, pr, rc, acc_cat, \
-            output_images_pred_corrected, loss_shape_corrected, pr_corrected, rc_corrected, acc_cat_corrected = model.getEval(
-                inputs=inputs, category_vectors=category_vectors, missing_prob=missing_pr)
-        loss_temp = [float(v) for v in (loss_shape, pr, rc, acc_cat, loss_shape_corrected, pr_corrected, rc_corrected, acc_cat_corrected)]
-        end_time = time.time()
-        loss = (loss * iteration + np.array(loss_temp)) / (iteration + 1.0)
-        run_time = (run_time * iteration + (end_time - start_time)) / (iteration + 1.0)
-        sys.stdout.write("it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(int(iteration + 1), run_time, int(epoch + 1)))
-        sys.stdout.write("cur_o/tot_o:{:05d}/{:05d} ".format(data_start, data_length))
-        sys.stdout.write("loss:{:.4f}, pr:{:.4f}, rc:{:.4f}, c:{:.4f}, ".format(loss[0], loss[1], loss[2], loss[3]))
-        sys.stdout.write("closs:{:.4f}, cpr:{:.4f}, crc:{:.4f}, cc:{:.4f}  \r".format(loss[4], loss[5], loss[6], loss[7]))
-        sys.stdout.flush()
-        if np.sum(loss) != np.sum(loss):
-            print('')
-            print('NaN')
-            return
-        iteration += 1.0
-        if max_iter is not None and iteration >= max_iter:
+    for epoch, position, total in C.epochs_of(loader, 1, 'batchStart'):
+        bar.tic()
+        batch = loader.getNextBatch(batch_size)
+        out = model.getEval(inputs=(batch['input_images'], batch['output_images'], batch['class_list']),
+                            category_vectors=category_vectors, missing_prob=missing_pr)
+        means.add(eval=out[1:5] + out[6:10])
+        bar.toc()
+        m = means['eval']
+        bar.show(epoch, position, total, bar.group(zip(('loss', 'pr', 'rc', 'c'), m[:4])) + ",",
+                 bar.group(zip(('closs', 'cpr', 'crc', 'cc'), m[4:])))
+        if C.stop_on_nan(means):
+            return None
+        if max_iter is not None and means.n >= max_iter:
             break
     print('')
-    return loss
+    return means['eval']
 
 
 latent_dim = 16

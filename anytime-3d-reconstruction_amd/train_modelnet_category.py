@@ -1,10 +1,7 @@
-"""Entry point mirroring the reference's train_modelnet_category.py (loop :47-107, config :109-139): the VAE with a
-learned class-conditional prior (nolboSingleObject_modelnet_category_only).
+"""Entry point with the role of the reference's train_modelnet_category.py (loop :47-107, config :109-139): the VAE with
+a learned class-conditional prior (nolboSingleObject_modelnet_category_only); `dropout=True` is train_modelnet_category_dr.py.
 `python train_modelnet_category.py --voxel 32 --batch 64 --max-iter 10`."""
 import sys
-import time
-
-import numpy as np
 
 import _entry_common as C
 import voxvae
@@ -33,64 +30,48 @@ def train(
     import src.module.nolbo as nolbo
     model = nolbo.nolboSingleObject_modelnet_category_only(nolbo_structure=config, learning_rate=learning_rate)
     voxel = config['encoder']['input_shape'][0]
-    data_loader_train = dataLoader(data_path=dataset_path, trainortest='train', voxel=voxel)
-    data_loader_test = dataLoader(data_path=dataset_path, trainortest='test', voxel=voxel)
-    if load_path != None:
+    loaders = {split: dataLoader(data_path=dataset_path, trainortest=split, voxel=voxel) for split in ('train', 'test')}
+    if load_path is not None:
         print('load weights...')
         model.loadModel(load_path=load_path)
         print('done!')
 
-    loss = np.zeros(5)
-    loss_train, loss_test = np.zeros(4), np.zeros(4)
-    epoch = 0.
-    iteration, run_time, total_iter = 0., 0., 0
-    print('start training...')
-    while epoch < training_epoch:
-        start_time = time.time()
-        epoch_curr = data_loader_train.epoch
-        data_start = data_loader_train.batchStart
-        data_length = data_loader_train.dataLength
-        batch_data = data_loader_train.getNextBatch(batchSize=batch_size)
-        batch_data_test = data_loader_test.getNextBatch(batchSize=batch_size)
-        inputs = batch_data['input_images'], batch_data['input_images'], batch_data['class_list']
-        inputs_test = batch_data_test['input_images'], batch_data_test['input_images'], batch_data_test['class_list']
-        if epoch != epoch_curr and iteration != 0:
-            print('')
-            iteration = 0
-            loss, loss_train, loss_test = loss * 0., loss_train * 0., loss_test * 0.
-            run_time = 0.
-            if save_path != None:
-                print('save model...')
-                model.saveModel(save_path=save_path)
-        epoch = epoch_curr
+    means = C.RunningMeans(fit=5, train=4, test=4)
+    bar = C.Progress()
 
-        loss_temp = [float(v) for v in model.fit(inputs=inputs, dropout=dropout)]
-        loss_train_temp = [float(v) for v in model.getEval(inputs=inputs)[1:5]]
-        loss_test_temp = [float(v) for v in model.getEval(inputs=inputs_test)[1:5]]
-        end_time = time.time()
-        loss = (loss * iteration + np.array(loss_temp)) / (iteration + 1.0)
-        loss_train = (loss_train * iteration + np.array(loss_train_temp)) / (iteration + 1.0)
-        loss_test = (loss_test * iteration + np.array(loss_test_temp)) / (iteration + 1.0)
-        run_time = (run_time * iteration + (end_time - start_time)) / (iteration + 1.0)
-        sys.stdout.write("it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(int(iteration + 1), run_time, int(epoch + 1)))
-        sys.stdout.write("cur_o/tot_o:{:04d}/{:04d} ".format(data_start, data_length))
-        sys.stdout.write("kl:{:.4f}, shape:{:.4f}, reg:{:.4f}, pr:{:.4f}, rc:{:.4f}, c:{:.4f} ".format(
-            loss[0], loss[1], loss[2], loss[3], loss[4], loss_train[3]))
-        sys.stdout.write("shape:{:.4f}, pr:{:.4f}, rc:{:.4f}, c:{:.4f}  \r".format(
-            loss_test[0], loss_test[1], loss_test[2], loss_test[3]))
-        sys.stdout.flush()
-        if np.sum(loss) != np.sum(loss):
-            print('')
-            print('NaN')
-            return
-        iteration += 1.0
-        total_iter += 1
-        if max_iter is not None and total_iter >= max_iter:
+    def new_epoch():
+        print('')
+        means.reset()
+        bar.reset()
+        if save_path is not None:
+            print('save model...')
+            model.saveModel(save_path=save_path)
+
+    def triple(batch):
+        return batch['input_images'], batch['input_images'], batch['class_list']
+
+    print('start training...')
+    done = 0
+    for epoch, position, total in C.epochs_of(loaders['train'], training_epoch, 'batchStart', new_epoch):
+        bar.tic()
+        inputs = triple(loaders['train'].getNextBatch(batchSize=batch_size))
+        inputs_test = triple(loaders['test'].getNextBatch(batchSize=batch_size))
+        fit = model.fit(inputs=inputs, dropout=dropout)
+        means.add(fit=fit, train=model.getEval(inputs=inputs)[1:5], test=model.getEval(inputs=inputs_test)[1:5])
+        bar.toc()
+        f, tr, te = means['fit'], means['train'], means['test']
+        bar.show(epoch, position, total,
+                 bar.group([('kl', f[0]), ('shape', f[1]), ('reg', f[2]), ('pr', f[3]), ('rc', f[4]), ('c', tr[3])]),
+                 bar.group([('shape', te[0]), ('pr', te[1]), ('rc', te[2]), ('c', te[3])]))
+        if C.stop_on_nan(means):
+            return None
+        done += 1
+        if max_iter is not None and done >= max_iter:
             break
     print('')
-    if save_path != None:
+    if save_path is not None:
         model.saveModel(save_path=save_path)
-    return loss, loss_train, loss_test
+    return means['fit'], means['train'], means['test']
 
 
 latent_dim = 64

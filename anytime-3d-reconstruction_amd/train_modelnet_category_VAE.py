@@ -1,9 +1,7 @@
-"""Entry point mirroring the reference's train_modelnet_category_VAE.py (control flow :22-107, config :109-132,
-printed fields :92-100) on the MI355X path.  `python train_modelnet_category_VAE.py --voxel 32 --batch 64`."""
+"""Entry point with the role of the reference's train_modelnet_category_VAE.py (control flow :22-107, config :109-132,
+printed fields :92-100) on the MI355X path; `model_class='AE'` gives train_modelnet_category_AE.py, `dropout=True` the
+_dr variants.  `python train_modelnet_category_VAE.py --voxel 32 --batch 64 --dtype bf16`."""
 import sys
-import time
-
-import numpy as np
 
 import _entry_common as C
 import voxvae
@@ -20,88 +18,52 @@ def train(
         max_iter=None, model_class='VAE', dropout=False,
 ):
     import src.module.nolbo as nolbo
-    cls = nolbo.nolboSingleObject_modelnet_category_VAE if model_class == 'VAE' else nolbo.nolboSingleObject_modelnet_category_AE
-    model = cls(nolbo_structure=config, learning_rate=learning_rate, dropout=dropout)   # dropout=True: the _dr scripts
+    variational = model_class == 'VAE'
+    cls = nolbo.nolboSingleObject_modelnet_category_VAE if variational else nolbo.nolboSingleObject_modelnet_category_AE
+    model = cls(nolbo_structure=config, learning_rate=learning_rate, dropout=dropout)
     voxel = config['encoder']['input_shape'][0]
-    data_loader_train = dataLoader(data_path=dataset_path, trainortest='train', voxel=voxel)
-    data_loader_test = dataLoader(data_path=dataset_path, trainortest='test', voxel=voxel)
-
-    if load_path != None:
+    loaders = {split: dataLoader(data_path=dataset_path, trainortest=split, voxel=voxel) for split in ('train', 'test')}
+    if load_path is not None:
         print('load weights...')
         model.loadModel(load_path=load_path)
         print('done!')
-
-    if load_decoder_path != None:
+    if load_decoder_path is not None:
         print('load decoder weights...')
         model.loadDecoder(load_path=load_decoder_path, file_name=load_decoder_name)
         print('done!')
-    nloss = 4 if model_class == 'VAE' else 3
-    loss = np.zeros(nloss)
-    loss_train, loss_test = np.zeros(3), np.zeros(3)
-    epoch = 0.
-    iteration, run_time = 0., 0.
-    total_iter = 0
+
+    means = C.RunningMeans(fit=4 if variational else 3, train=3, test=3)
+    bar = C.Progress()
+
+    def new_epoch():
+        print('')
+        means.reset()
+        bar.reset()
+        if save_path is not None:
+            print('save model...')
+            model.saveModel(save_path=save_path)
 
     print('start training...')
-    while epoch < training_epoch:
-        start_time = time.time()
-        epoch_curr = data_loader_train.epoch
-        data_start = data_loader_train.batchStart
-        data_length = data_loader_train.dataLength
-
-        batch_data = data_loader_train.getNextBatch(batchSize=batch_size)
-        batch_data_test = data_loader_test.getNextBatch(batchSize=batch_size)
-        input_images, output_images = batch_data['input_images'], batch_data['input_images']
-        inputs = input_images, output_images
-        input_images_test, output_images_test = batch_data_test['input_images'], batch_data_test['input_images']
-        inputs_test = input_images_test, output_images_test
-
-        if epoch != epoch_curr and iteration != 0:
-            print('')
-            iteration = 0
-            loss, loss_train, loss_test = loss * 0., loss_train * 0., loss_test * 0.
-            run_time = 0.
-            if save_path != None:
-                print('save model...')
-                model.saveModel(save_path=save_path)
-        epoch = epoch_curr
-
-        loss_temp = model.fit(inputs=inputs)
-        loss_train_temp = model.getEval(inputs=inputs)[1:]
-        loss_test_temp = model.getEval(inputs=inputs_test)[1:]
-        end_time = time.time()
-
-        loss = (loss * iteration + np.array(loss_temp)) / (iteration + 1.0)
-        loss_train = (loss_train * iteration + np.array(loss_train_temp)) / (iteration + 1.0)
-        loss_test = (loss_test * iteration + np.array(loss_test_temp)) / (iteration + 1.0)
-        run_time = (run_time * iteration + (end_time - start_time)) / (iteration + 1.0)
-
-        sys.stdout.write(
-            "it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(int(iteration + 1), run_time, int(epoch + 1)))
-        sys.stdout.write("cur_o/tot_o:{:04d}/{:04d} ".format(data_start, data_length))
-        if model_class == 'VAE':
-            sys.stdout.write(
-                "kl:{:.4f}, shape:{:.4f}, pr:{:.4f}, rc:{:.4f} ".format(
-                    loss[0], loss_train[0], loss_train[1], loss_train[2]))
-        else:
-            sys.stdout.write(
-                "shape:{:.4f}, pr:{:.4f}, rc:{:.4f} ".format(loss_train[0], loss_train[1], loss_train[2]))
-        sys.stdout.write(
-            "shape:{:.4f}, pr:{:.4f}, rc:{:.4f}  \r".format(
-                loss_test[0], loss_test[1], loss_test[2]))
-        sys.stdout.flush()
-
-        if np.sum(loss) != np.sum(loss):
-            print('')
-            print('NaN')
-            return
-        iteration += 1.0
-        total_iter += 1
-        if max_iter is not None and total_iter >= max_iter:
-            print('')
-            if save_path != None:
-                model.saveModel(save_path=save_path)
-            return loss, loss_train, loss_test
+    done = 0
+    for epoch, position, total in C.epochs_of(loaders['train'], training_epoch, 'batchStart', new_epoch):
+        bar.tic()
+        x = loaders['train'].getNextBatch(batchSize=batch_size)['input_images']
+        x_test = loaders['test'].getNextBatch(batchSize=batch_size)['input_images']
+        fit = model.fit(inputs=(x, x))
+        means.add(fit=fit, train=model.getEval(inputs=(x, x))[1:], test=model.getEval(inputs=(x_test, x_test))[1:])
+        bar.toc()
+        tr, te = means['train'], means['test']
+        first = ([('kl', means['fit'][0])] if variational else []) + [('shape', tr[0]), ('pr', tr[1]), ('rc', tr[2])]
+        bar.show(epoch, position, total, bar.group(first), bar.group([('shape', te[0]), ('pr', te[1]), ('rc', te[2])]))
+        if C.stop_on_nan(means):
+            return None
+        done += 1
+        if max_iter is not None and done >= max_iter:
+            break
+    print('')
+    if save_path is not None:
+        model.saveModel(save_path=save_path)
+    return means['fit'], means['train'], means['test']
 
 
 latent_dim = 64
@@ -115,4 +77,4 @@ if __name__ == '__main__':
         config=C.make_config(a.latent, a.voxel, True),
         dataset_path=a.dataset_path,
         save_path=a.save_path, load_path=a.load_path, max_iter=a.max_iter,
-    ) is not None or a.max_iter is None else 1)
+    ) is not None else 1)

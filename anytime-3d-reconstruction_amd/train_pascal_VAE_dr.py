@@ -3,10 +3,8 @@ dropout=True (random-rate latent dropout, nolbo.py:801-803) trained on (image, v
 evaluates the current train and validation batches with the legacy getEval(inputs)[1:] form.
 `python train_pascal_VAE_dr.py --batch 8 --image 128 --voxel 32 --max-iter 3`."""
 import sys
-import time
 
-import numpy as np
-
+import _entry_common as C
 import voxvae
 import src.dataset_loader.pascal3D as pascal3D
 import src.net_core.darknet as Darknet
@@ -26,65 +24,48 @@ def train(
     model = nolbo.nolboSingleObject_VAE(nolbo_structure=config, backbone_style=Darknet.Darknet19, learning_rate=learning_rate,
                                         dropout=True)
     voxel = config['decoder']['output_shape'][0]
-    data_loader_pascal_train = pascal3D.dataLoaderSingleObject(trainOrVal='train', Pascal3DDataPath=dataset_path, voxel=voxel)
-    data_loader_pascal_test = pascal3D.dataLoaderSingleObject(trainOrVal='val', Pascal3DDataPath=dataset_path, voxel=voxel)
-    if load_path != None:
+    loaders = {split: pascal3D.dataLoaderSingleObject(trainOrVal=split, Pascal3DDataPath=dataset_path, voxel=voxel)
+               for split in ('train', 'val')}
+    if load_path is not None:
         print('load weights...')
         model.loadModel(load_path=load_path)
         print('done!')
-    if load_encoder_backbone_path != None:
+    if load_encoder_backbone_path is not None:
         model.loadEncoderBackbone(load_path=load_encoder_backbone_path, file_name=load_encoder_backbone_name)
-    if load_decoder_path != None:
+    if load_decoder_path is not None:
         model.loadDecoder(load_path=load_decoder_path, file_name=load_decoder_name)
 
-    loss = np.zeros(4)
-    loss_train, loss_test = np.zeros(3), np.zeros(3)
-    epoch = 0.
-    iteration, run_time, total_it = 0., 0., 0
-    print('start training...')
-    while epoch < training_epoch:
-        start_time = time.time()
-        epoch_curr = data_loader_pascal_train.epoch
-        data_start = data_loader_pascal_train.dataStart
-        data_length = data_loader_pascal_train.dataLength
-        batch_data = data_loader_pascal_train.getNextBatch(batchSizeof3DShape=batch_size, imageSize=image_size)
-        batch_data_test = data_loader_pascal_test.getNextBatch(batchSizeof3DShape=batch_size, imageSize=image_size, augmentation=False)
-        inst_list, category_list, sin, cos, input_images, output_images = batch_data
-        inputs = input_images, output_images
-        inputs_test = batch_data_test[4], batch_data_test[5]
-        if epoch != epoch_curr and iteration != 0:
-            print('')
-            iteration = 0
-            loss, loss_train, loss_test = loss * 0., loss_train * 0., loss_test * 0.
-            run_time = 0.
-            if save_path != None:
-                print('save model...')
-                model.saveModel(save_path=save_path)
-        epoch = epoch_curr
+    means = C.RunningMeans(fit=4, train=3, test=3)
+    bar = C.Progress()
 
-        loss_temp = model.fit(inputs=inputs)
-        loss_train_temp = [float(v) for v in model.getEval(inputs=inputs)[1:]]
-        loss_test_temp = [float(v) for v in model.getEval(inputs=inputs_test)[1:]]
-        end_time = time.time()
-        loss = (loss * iteration + np.array(loss_temp)) / (iteration + 1.0)
-        loss_train = (loss_train * iteration + np.array(loss_train_temp)) / (iteration + 1.0)
-        loss_test = (loss_test * iteration + np.array(loss_test_temp)) / (iteration + 1.0)
-        run_time = (run_time * iteration + (end_time - start_time)) / (iteration + 1.0)
-        sys.stdout.write("it:{:04d} rt:{:.2f} Ep_o:{:03d} ".format(int(iteration + 1), run_time, int(epoch + 1)))
-        sys.stdout.write("cur_o/tot_o:{:04d}/{:04d} ".format(data_start, data_length))
-        sys.stdout.write("kl:{:.4f}, shape:{:.4f}, pr:{:.4f}, rc:{:.4f} ".format(loss[0], loss_train[0], loss_train[1], loss_train[2]))
-        sys.stdout.write("shape:{:.4f}, pr:{:.4f}, rc:{:.4f}  \r".format(loss_test[0], loss_test[1], loss_test[2]))
-        sys.stdout.flush()
-        if np.sum(loss) != np.sum(loss):
-            print('')
-            print('NaN')
-            return
-        iteration += 1.0
-        total_it += 1
-        if max_iter is not None and total_it >= max_iter:
+    def new_epoch():
+        print('')
+        means.reset()
+        bar.reset()
+        if save_path is not None:
+            print('save model...')
+            model.saveModel(save_path=save_path)
+
+    print('start training...')
+    done = 0
+    for epoch, position, total in C.epochs_of(loaders['train'], training_epoch, 'dataStart', new_epoch):
+        bar.tic()
+        batch = loaders['train'].getNextBatch(batchSizeof3DShape=batch_size, imageSize=image_size)
+        batch_val = loaders['val'].getNextBatch(batchSizeof3DShape=batch_size, imageSize=image_size, augmentation=False)
+        pair, pair_val = (batch[4], batch[5]), (batch_val[4], batch_val[5])          # (input_images, output_images)
+        fit = model.fit(inputs=pair)
+        means.add(fit=fit, train=model.getEval(inputs=pair)[1:], test=model.getEval(inputs=pair_val)[1:])
+        bar.toc()
+        tr, te = means['train'], means['test']
+        bar.show(epoch, position, total, bar.group([('kl', means['fit'][0]), ('shape', tr[0]), ('pr', tr[1]), ('rc', tr[2])]),
+                 bar.group([('shape', te[0]), ('pr', te[1]), ('rc', te[2])]))
+        if C.stop_on_nan(means):
+            return None
+        done += 1
+        if max_iter is not None and done >= max_iter:
             break
     print('')
-    return loss, loss_train, loss_test
+    return means['fit'], means['train'], means['test']
 
 
 if __name__ == '__main__':
