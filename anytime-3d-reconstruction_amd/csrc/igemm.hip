@@ -182,17 +182,23 @@ __device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, 
     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], bf[q], acc, 0, 0, 0);
 }
 
-template <typename T, int MODE, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+template <typename T, int MODE, int BM, int BN, int STAGES, int KH>
+__global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
+    // KH = 2: two 4-wave halves of one 512-thread workgroup share the output tile and take alternate K chunks, each
+    // through its own staging buffers; at the end the second half hands its accumulators over through LDS.  Same waves
+    // per CU as two split-K workgroups, but no slabs in HBM and no separate reduce pass.
+    static_assert(KH == 1 || (KH == 2 && STAGES == 2 && MODE != MODE_FIRST), "the two-half form uses the 2-stage LDS-DMA loop");
     constexpr int BK = Elt<T>::BK;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 tiles per wave (waves laid out 2 x 2)
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
     constexpr bool DMA = MODE != MODE_FIRST;   // global -> LDS directly (global_load_lds_dwordx4), no VGPR round trip
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *As = smem;                            // [STAGES][BM][128]
-    char *Bs = smem + STAGES * BM * ROWB;       // [STAGES][BN][128]
+    constexpr int HB = STAGES * (BM + BN) * ROWB;   // staging bytes of one half
+    const int half = KH == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    char *As = smem + half * HB;                // [STAGES][BM][128]
+    char *Bs = As + STAGES * BM * ROWB;         // [STAGES][BN][128]
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;   // role inside the half
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so block b
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // is exactly what a tap in the SAME padding (or a row past M / N / K) must contribute -- no zero page, no branches.
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const u32x4 rsA = vv_make_rsrc(a.A, a.a_bytes), rsW = vv_make_rsrc(a.W, a.w_bytes);
-    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;   // LDS byte address of the staging area
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem + half * HB;   // LDS byte address of this half's staging area
     int aoff[RA];                     // byte offset of (row, tap 0, channel 0, this lane's slot); garbage where never valid
     unsigned long long rmask[RA];     // per-tap validity of the row
 #pragma unroll
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         woff[i] = (n0 + r0 + 32 * i < a.N) ? (unsigned)(((size_t)parity * a.N + n0 + r0 + 32 * i) * a.K * sizeof(T)) + gchunk * 16 : OOB;
 
     // Tile-uniform list of taps that touch real data for at least one row (smem tail, lives through the K loop).
-    int *taplist = reinterpret_cast<int *>(smem + STAGES * (BM + BN) * ROWB);   // [64] + 2 mask words
+    int *taplist = reinterpret_cast<int *>(smem + KH * HB);   // [64] + 2 mask words
     int nvalid = kc_end - kc_begin, vb = kc_begin;                         // dense / first: chunks are the list
     if constexpr (TAPS) {
         unsigned *mw = reinterpret_cast<unsigned *>(taplist + 64);
@@ -267,11 +273,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     // ---- DMA path: one buffer_load_dwordx4 ... lds per staged row per thread; a wave instruction fills 8 rows (1 KiB).
     // Per chunk and row: test one bit, add the wave-uniform tap delta, select OOB.  Weights: the delta rides in soffset.
-    auto issue = [&](int vi, int buf) {
+    auto issue = [&](int vi, int buf, bool live = true) {     // live == false: deposit zeros (a half without a chunk left)
         int tap = 0, kc = vi, delta;
         if constexpr (TAPS) {
             const int sub = vi & ((1 << a.cpt_log2) - 1);
-            tap = __builtin_amdgcn_readfirstlane(taplist[vi >> a.cpt_log2]);
+            tap = live ? __builtin_amdgcn_readfirstlane(taplist[vi >> a.cpt_log2]) : 0;
             kc = (tap << a.cpt_log2) + sub;
             const int li = a.din_log2;
             int toff;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         } else {
             delta = kc * ROWB;
         }
-        const bool kin = (MODE != MODE_DENSE) || (kc * BK + gchunk * (BK / 8) < a.K);
+        const bool kin = live && ((MODE != MODE_DENSE) || (kc * BK + gchunk * (BK / 8) < a.K));
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             bool v;
@@ -391,6 +397,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             st = st + 1 == STAGES ? 0 : st + 1;
         }
         __syncthreads();
+    } else if constexpr (KH == 2) {
+        // both halves run the same number of steps (one barrier each); half h takes chunks vb + 2 i + h
+        const int nsteps = (ve - vb + 1) >> 1;
+        auto issue_step = [&](int i, int buf) { const int v = vb + 2 * i + half; issue(v < ve ? v : vb, buf, v < ve); };
+        if (nsteps > 0) issue_step(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int i = 0; i < nsteps; ++i) {
+            if (i + 1 < nsteps) issue_step(i + 1, buf ^ 1);
+            compute(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+        // hand-over: thread t of the second half parks its accumulators where thread t of the first half picks them up
+        // (16 bytes per lane per step: conflict-free), over the staging area nobody reads any more
+        f32x4 *xch = reinterpret_cast<f32x4 *>(smem);
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        xch[((i * TN + j) * 4 + g) * 256 + tid] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = xch[((i * TN + j) * 4 + g) * 256 + tid];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += v[e];
+                }
+        __syncthreads();          // (first half only from here on) the epilogue tile reuses the same bytes
     } else {
         if (vi < ve) {
             if constexpr (DMA) issue(vi, 0);
@@ -543,7 +589,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, 
 }
 
 struct Plan {
-    int bm, bn, split, cps, nparity;
+    int bm, bn, split, cps, nparity, kh;
     size_t ws_bytes;
 };
 
@@ -559,6 +605,11 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     static const long target = getenv("VV_SPLIT_TARGET") ? atol(getenv("VV_SPLIT_TARGET")) : 512;
     int split = 1;
     while (tiles * split < target && split * 2 <= nchunks / 8 && split < 64) split *= 2;
+    // The first factor of two is taken INSIDE the workgroup (two 4-wave halves on alternate chunks, accumulators handed
+    // over through LDS): same waves per CU, half the slabs -- or none, and then no reduce pass at all.
+    static const bool no_kh = getenv("VV_NO_KHALVES") != nullptr;
+    p.kh = 1;
+    if (split >= 2 && mode != MODE_FIRST && !no_kh) { p.kh = 2; split /= 2; }
     p.cps = (nchunks + split - 1) / split;
     p.split = (nchunks + p.cps - 1) / p.cps;
     p.ws_bytes = p.split > 1 ? (size_t)p.split * p.nparity * M * N * sizeof(float) : 0;
@@ -575,20 +626,18 @@ bool use_pos_major(int mode, int din, int batch) {
     return false;
 }
 
-template <typename T, int MODE, int BN, int STAGES>
+template <typename T, int MODE, int BN, int STAGES, int KH>
 void launch_k(const IgemmArgs &a, dim3 grid, hipStream_t st) {
-    size_t lds = (size_t)STAGES * (128 + BN) * ROWB + 272;   // stages + tap list
-    const size_t lds_epi = (size_t)128 * (BN * 4 + 16);
-    if (lds_epi > lds) lds = lds_epi;
+    constexpr size_t stage_bytes = (size_t)KH * STAGES * (128 + BN) * ROWB + 272;   // staging of every half + tap list
+    constexpr size_t epi_bytes = (size_t)128 * (BN * 4 + 16);
+    constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static const bool attr_set = [] {
-        size_t m = (size_t)STAGES * (128 + BN) * ROWB + 272;
-        if ((size_t)128 * (BN * 4 + 16) > m) m = (size_t)128 * (BN * 4 + 16);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, BN, STAGES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)m);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<T, MODE, 128, BN, STAGES, KH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return true;
     }();
     (void)attr_set;
-    VV_LAUNCH((igemm_kernel<T, MODE, 128, BN, STAGES>), grid, dim3(256), lds, st, a);
+    VV_LAUNCH((igemm_kernel<T, MODE, 128, BN, STAGES, KH>), grid, dim3(256 * KH), lds, st, a);
 }
 
 template <typename T, int MODE>
@@ -597,14 +646,19 @@ int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     dim3 grid(tiles * p.split * p.nparity);
     static const int stages_env = getenv("VV_STAGES") ? atoi(getenv("VV_STAGES")) : 2;
     const int stages = (MODE == MODE_FIRST || sizeof(T) == 4) ? 2 : stages_env;   // deep ring: bf16 LDS-DMA modes only
-    if (p.bn == 128) {
-        if (stages == 3) launch_k<T, MODE, 128, 3>(a, grid, st);
-        else if (stages == 4) launch_k<T, MODE, 128, 4>(a, grid, st);
-        else launch_k<T, MODE, 128, 2>(a, grid, st);
+    if (p.kh == 2) {
+        if constexpr (MODE != MODE_FIRST) {
+            if (p.bn == 128) launch_k<T, MODE, 128, 2, 2>(a, grid, st);
+            else launch_k<T, MODE, 64, 2, 2>(a, grid, st);
+        }
+    } else if (p.bn == 128) {
+        if (stages == 3) launch_k<T, MODE, 128, 3, 1>(a, grid, st);
+        else if (stages == 4) launch_k<T, MODE, 128, 4, 1>(a, grid, st);
+        else launch_k<T, MODE, 128, 2, 1>(a, grid, st);
     } else {
-        if (stages == 3) launch_k<T, MODE, 64, 3>(a, grid, st);
-        else if (stages == 4) launch_k<T, MODE, 64, 4>(a, grid, st);
-        else launch_k<T, MODE, 64, 2>(a, grid, st);
+        if (stages == 3) launch_k<T, MODE, 64, 3, 1>(a, grid, st);
+        else if (stages == 4) launch_k<T, MODE, 64, 4, 1>(a, grid, st);
+        else launch_k<T, MODE, 64, 2, 1>(a, grid, st);
     }
     if (p.split > 1) {
         const size_t total = (size_t)p.nparity * a.M * (a.N / 4);
