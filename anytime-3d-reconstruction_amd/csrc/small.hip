@@ -16,6 +16,65 @@ __global__ void pack_conv_k4_kernel(const float *__restrict__ w, T *__restrict__
     }
 }
 
+// The same transposition through a 64 x 64 LDS tile (cout % 64 == 0; K = 64 cin always is): float4 reads along co,
+// 16 consecutive k per thread on the way out -- both sides coalesced (the element-wise form reads with a stride of cout
+// floats and spent 36 us on the 8 M-element layer).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_k4_tiled_kernel(const float *__restrict__ w, T *__restrict__ out, int cin, int cout) {
+    __shared__ float tile[64][65];
+    const int K = 64 * cin, tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+    const int c4 = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kl = r + 16 * j;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + (size_t)(k0 + kl) * cout + co0 + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[kl][4 * c4 + e] = v[e];
+    }
+    __syncthreads();
+    const int col = tid >> 2, kq = (tid & 3) * 16;
+    T *dst = out + (size_t)(co0 + col) * K + k0 + kq;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        const f32x4 v = {tile[kq + e][col], tile[kq + e + 1][col], tile[kq + e + 2][col], tile[kq + e + 3][col]};
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<f32x4 *>(dst + e) = v;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = static_cast<__bf16>(v[u]);
+            *reinterpret_cast<bf16x4 *>(dst + e) = o;
+        }
+    }
+}
+
+// four consecutive ci per thread (cin % 4 == 0): 16-byte reads, 8/16-byte writes, a quarter of the index arithmetic
+template <typename T>
+__global__ void pack_convT_k4s2_vec_kernel(const float *__restrict__ w, T *__restrict__ out, int cin, int cout) {
+    const int K = 8 * cin, K4 = K >> 2;
+    const size_t total4 = (size_t)8 * cout * K4;
+    for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i4 % K4) * 4;
+        const size_t pc = i4 / K4;
+        const int co = (int)(pc % cout), p = (int)(pc / cout);
+        const int a = k / cin, ci = k % cin;
+        const int td = 1 - ((p >> 2) & 1) + 2 * ((a >> 2) & 1);
+        const int th = 1 - ((p >> 1) & 1) + 2 * ((a >> 1) & 1);
+        const int tw = 1 - (p & 1) + 2 * (a & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + ((size_t)t * cout + co) * cin + ci);
+        if constexpr (sizeof(T) == 4) {
+            reinterpret_cast<f32x4 *>(out)[i4] = v;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = static_cast<__bf16>(v[u]);
+            reinterpret_cast<bf16x4 *>(out)[i4] = o;
+        }
+    }
+}
+
 template <typename T>
 __global__ void pack_convT_k4s2_kernel(const float *__restrict__ w, T *__restrict__ out, int cin, int cout) {
     // out[p][co][a*cin + ci] = w[t(p,a)][co][ci],  t = 1 - p + 2a per axis
@@ -220,11 +279,20 @@ VV_EXPORT const char *vv_status_string(int s) {
 
 VV_EXPORT int vv_pack_conv_k4(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream) {
     if (cin <= 0 || cout <= 0) return VV_ERR_SHAPE;
+    if (w_keras && packed && cout % 64 == 0 && (dtype == VV_F32 || dtype == VV_BF16) && vv_aligned16(w_keras) && vv_aligned16(packed)) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const dim3 grid(cin, cout / 64);                 // K / 64 = cin
+        if (dtype == VV_BF16) VV_LAUNCH(pack_conv_k4_tiled_kernel<__bf16>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<__bf16 *>(packed), cin, cout);
+        else VV_LAUNCH(pack_conv_k4_tiled_kernel<float>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<float *>(packed), cin, cout);
+        return vv_launch_status();
+    }
     VV_PACK_DISPATCH(pack_conv_k4_kernel, (size_t)64 * cin * cout, cin, cout);
 }
 
 VV_EXPORT int vv_pack_convT_k4s2(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream) {
     if (cin <= 0 || cout <= 0) return VV_ERR_SHAPE;
+    if (cin % 4 == 0 && vv_aligned16(w_keras) && vv_aligned16(packed))
+        VV_PACK_DISPATCH(pack_convT_k4s2_vec_kernel, (size_t)16 * cin * cout, cin, cout);
     VV_PACK_DISPATCH(pack_convT_k4s2_kernel, (size_t)64 * cin * cout, cin, cout);
 }
 

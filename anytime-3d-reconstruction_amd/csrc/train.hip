@@ -102,19 +102,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x,
     }
 }
 
-// Sum of the per-block partials of 16 channels in double, by 256 threads = 16 channels x 16 slices of the block list;
-// the 16 slice sums of a channel are added in slice order (deterministic).  Result valid in threads 0..15 (channel = tid).
+// Sum of the per-block partials of BN_FC channels in double, by 256 threads = 4 channels x 64 slices of the block list
+// (a 1024-block list costs 16 trips of 4 independent loads, not 64 dependent ones); the 64 slice sums of a channel are
+// added in slice order (deterministic).  Result valid in threads 0..3 (channel = c0 + tid).
+constexpr int BN_FC = 4;
 __device__ __forceinline__ void bn_partial_sums(const float *__restrict__ partial, int nblk, int C, int c0, double &s, double &ss) {
-    __shared__ double red[2][16][17];
-    const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4, c = c0 + cl;
+    __shared__ double red[2][64][BN_FC + 1];
+    const int tid = threadIdx.x, cl = tid & (BN_FC - 1), sl = tid >> 2, c = c0 + cl;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int k = sl; k < nblk; k += 16) { a += partial[((size_t)k * 2) * C + c]; b += partial[((size_t)k * 2 + 1) * C + c]; }
+    if (c < C) {
+        int k = sl;
+        for (; k + 192 < nblk; k += 256) {
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = partial[((size_t)(k + 64 * u) * 2) * C + c];
+                vb[u] = partial[((size_t)(k + 64 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; k < nblk; k += 64) { a += partial[((size_t)k * 2) * C + c]; b += partial[((size_t)k * 2 + 1) * C + c]; }
+    }
     red[0][sl][cl] = a; red[1][sl][cl] = b;
     __syncthreads();
     s = 0.0; ss = 0.0;
-    if (tid < 16)
-        for (int k = 0; k < 16; ++k) { s += red[0][k][tid]; ss += red[1][k][tid]; }
+    if (tid < BN_FC)
+        for (int k = 0; k < 64; ++k) { s += red[0][k][tid]; ss += red[1][k][tid]; }
 }
 
 // Forward finalise: batch mean / biased variance -> scale, shift, rstd; moving statistics update (momentum).
@@ -122,9 +136,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float *__r
                                          const float *beta, float eps, float momentum, float *mean, float *var, float *rstd,
                                          float *scale, float *shift, float *moving_mean, float *moving_var) {
     double s, ss;
-    bn_partial_sums(partial, nblk, C, blockIdx.x * 16, s, ss);
-    const int c = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x >= 16 || c >= C) return;
+    bn_partial_sums(partial, nblk, C, blockIdx.x * BN_FC, s, ss);
+    const int c = blockIdx.x * BN_FC + threadIdx.x;
+    if (threadIdx.x >= BN_FC || c >= C) return;
     const double m = s / (double)R;
     double v = ss / (double)R - m * m;
     if (v < 0.0) v = 0.0;
@@ -139,9 +153,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float *__r
 // Backward finalise: dbeta = sum du, dgamma = sum du*xhat
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float *dgamma, float *dbeta) {
     double s, ss;
-    bn_partial_sums(partial, nblk, C, blockIdx.x * 16, s, ss);
-    const int c = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x >= 16 || c >= C) return;
+    bn_partial_sums(partial, nblk, C, blockIdx.x * BN_FC, s, ss);
+    const int c = blockIdx.x * BN_FC + threadIdx.x;
+    if (threadIdx.x >= BN_FC || c >= C) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
 }
@@ -447,8 +461,42 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__re
                                     int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {       // four loads in flight, added in split order
+            const float v0 = slabs[(size_t)k * n + i], v1 = slabs[(size_t)(k + 1) * n + i], v2 = slabs[(size_t)(k + 2) * n + i],
+                        v3 = slabs[(size_t)(k + 3) * n + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < splits; ++k) s += slabs[(size_t)k * n + i];
         out[i] = accumulate ? out[i] + alpha * s : alpha * s;
+    }
+}
+
+// Few outputs, many slabs (the single-channel layers: 4096 outputs x 256 splits): 64 outputs x 4 slices of the split
+// list per workgroup; the 4 slice sums are added in slice order.
+__global__ __launch_bounds__(256) void wgrad_reduce_sliced_kernel(const float *__restrict__ slabs, float *__restrict__ out, long n,
+                                                                  int splits, float alpha, int accumulate) {
+    __shared__ float red[4][64];
+    const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + ol;
+    const int per = (splits + 3) / 4, k0 = sl * per, k1 = k0 + per < splits ? k0 + per : splits;
+    float s = 0.f;
+    if (i < n) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < k1; ++k) s += slabs[(size_t)k * n + i];
+    }
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        const float t = ((red[0][ol] + red[1][ol]) + red[2][ol]) + red[3][ol];
+        out[i] = accumulate ? out[i] + alpha * t : alpha * t;
     }
 }
 
@@ -576,13 +624,27 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamChunk *__rest
 }
 
 template <typename T>
-__global__ void colsum_kernel(const T *__restrict__ x, float *__restrict__ out, long R, int C) {
-    // out[c] = sum_r x[r][c] (Dense bias gradient; R = batch, small)
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ x, float *__restrict__ out, long R, int C) {
+    // out[c] = sum_r x[r][c] (Dense bias gradient; R = batch): 32 columns x 8 row slices per workgroup, slice sums added in order
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (long r = 0; r < R; ++r) s += (float)x[r * C + c];
-    out[c] = s;
+    if (c < C) {
+        long r = sl;
+        for (; r + 24 < R; r += 32) {
+            const float v0 = (float)x[r * C + c], v1 = (float)x[(r + 8) * C + c], v2 = (float)x[(r + 16) * C + c], v3 = (float)x[(r + 24) * C + c];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; r < R; r += 8) s += (float)x[r * C + c];
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        out[c] = t;
+    }
 }
 
 inline int grid_1d(long n) {
@@ -590,14 +652,21 @@ inline int grid_1d(long n) {
     return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
-inline int bn_blocks(long R) {
-    long nb = (R + 255) / 256;
+// Row blocks of the two BatchNorm sweeps: 256 rows per block on the long layers (at most 1024 blocks), but never fewer
+// blocks than keep ~16 rows per block -- a 2048-row x 512-channel layer is 128 blocks, not 8.
+inline int bn_blocks(long R, int C) {
+    const int c4n = C >> 2;
+    const int rows_par = 256 / c4n > 0 ? 256 / c4n : 1;
+    long per = 8L * rows_par;                   // two trips of the 4-rows-in-flight loop
+    if (per < 16) per = 16;
+    if (per > 256) per = 256;
+    long nb = (R + per - 1) / per;
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 
 }  // namespace
 
-VV_EXPORT size_t vv_bn_workspace_bytes(long rows, int channels) { return (size_t)bn_blocks(rows) * 2 * channels * sizeof(float); }
+VV_EXPORT size_t vv_bn_workspace_bytes(long rows, int channels) { return (size_t)bn_blocks(rows, channels) * 2 * channels * sizeof(float); }
 
 VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const float *gamma, const float *beta, float eps,
                                 float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
@@ -607,7 +676,7 @@ VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const fl
     if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nb = bn_blocks(rows);
+    const int nb = bn_blocks(rows, channels);
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
     if (dtype == VV_BF16)
@@ -616,7 +685,7 @@ VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const fl
     else
         VV_LAUNCH((bn_reduce_kernel<0, float>), dim3(nb), dim3(256), 0, st, reinterpret_cast<const float *>(x), nullptr, nullptr, nullptr,
                   nullptr, nullptr, part, rows, channels, rpb, 0);
-    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, rows, channels, gamma, beta, eps,
+    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, rows, channels, gamma, beta, eps,
               momentum, mean, var, rstd, scale, shift, moving_mean, moving_var);
     return vv_launch_status();
 }
@@ -645,20 +714,20 @@ VV_EXPORT int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, c
     if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nb = bn_blocks(rows);
+    const int nb = bn_blocks(rows, channels);
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
     const long n4 = rows * channels / 4;
     if (dtype == VV_BF16) {
         const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *dyb = reinterpret_cast<const __bf16 *>(dy);
         VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
-        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
+        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
         VV_LAUNCH(bn_act_bwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, dgamma, dbeta,
                   reinterpret_cast<__bf16 *>(dx), n4, channels, 1.0f / (float)rows, act);
     } else {
         const float *xf = reinterpret_cast<const float *>(x), *dyf = reinterpret_cast<const float *>(dy);
         VV_LAUNCH((bn_reduce_kernel<1, float>), dim3(nb), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, part, rows, channels, rpb, act);
-        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + 15) / 16), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
+        VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
         VV_LAUNCH(bn_act_bwd_kernel<float>, dim3(grid_1d(n4)), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, dgamma, dbeta,
                   reinterpret_cast<float *>(dx), n4, channels, 1.0f / (float)rows, act);
     }
@@ -703,13 +772,20 @@ bool wgrad_bf16_ok(const void *A, const void *G, long R, int M, int N, int lda, 
     return vv_aligned16(A) && vv_aligned16(G);
 }
 
+void launch_wgrad_reduce(const float *slabs, float *out, long n, int splits, float alpha, int accumulate, hipStream_t st) {
+    if (splits >= 16 && n <= 65536)
+        VV_LAUNCH(wgrad_reduce_sliced_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, out, n, splits, alpha, accumulate);
+    else
+        VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, slabs, out, n, splits, alpha, accumulate);
+}
+
 template <int AMODE>
 int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha, int accumulate, hipStream_t st) {
     const int tiles = ((a.M + 63) / 64) * ((a.N + p.bn - 1) / p.bn);
     if (p.bn == 128) VV_LAUNCH((wgrad_kernel<AMODE, 128>), dim3(tiles, p.splits), dim3(256), 0, st, a);
     else VV_LAUNCH((wgrad_kernel<AMODE, 64>), dim3(tiles, p.splits), dim3(256), 0, st, a);
     const long n = (long)a.M * a.N;
-    VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, a.slabs, out, n, p.splits, alpha, accumulate);
+    launch_wgrad_reduce(a.slabs, out, n, p.splits, alpha, accumulate, st);
     return vv_launch_status();
 }
 
@@ -723,7 +799,7 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
     (void)attr;
     VV_LAUNCH((wgrad_bf16_kernel<AMODE>), dim3(tiles, p.splits), dim3(256), 65536, st, a);
     const long n = (long)a.M * a.N;
-    VV_LAUNCH(wgrad_reduce_kernel, dim3(grid_1d(n)), dim3(256), 0, st, a.slabs, out, n, p.splits, 1.f, 0);
+    launch_wgrad_reduce(a.slabs, out, n, p.splits, 1.f, 0, st);
     return vv_launch_status();
 }
 }  // namespace
@@ -847,7 +923,7 @@ VV_EXPORT int vv_colsum(const void *x, float *out, long rows, int cols, int dtyp
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
     if (rows <= 0 || cols <= 0) return VV_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == VV_BF16) VV_LAUNCH(colsum_kernel<__bf16>, dim3((cols + 255) / 256), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), out, rows, cols);
-    else VV_LAUNCH(colsum_kernel<float>, dim3((cols + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float *>(x), out, rows, cols);
+    if (dtype == VV_BF16) VV_LAUNCH(colsum_kernel<__bf16>, dim3((cols + 31) / 32), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), out, rows, cols);
+    else VV_LAUNCH(colsum_kernel<float>, dim3((cols + 31) / 32), dim3(256), 0, st, reinterpret_cast<const float *>(x), out, rows, cols);
     return vv_launch_status();
 }

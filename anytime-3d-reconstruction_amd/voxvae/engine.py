@@ -80,6 +80,7 @@ class _EngineBase:
         self.packed = {}
         self.ws = _Workspace(self.device)
         self._dirty = True
+        self._folded, self._want_fold = False, True
         self.act = L.ACT[structure['activation']]
         self.timer = None         # LayerTimer or None
         self.tag = ''
@@ -104,6 +105,8 @@ class _EngineBase:
         return {k: v.detach().cpu().numpy() for k, v in self.params.items()}
 
     def _fold(self, prefix, channels, repeat=1, bias=None):
+        if not self._want_fold:
+            return None, None
         p = self.params
         scale = torch.empty(channels * repeat, dtype=torch.float32, device=self.device)
         shift = torch.empty_like(scale)
@@ -115,10 +118,14 @@ class _EngineBase:
     def _empty(self, *shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
-    def ensure_packed(self):
-        if self._dirty:
+    def ensure_packed(self, fold=True):
+        """Refresh the packed weight images after a weight change.  fold=False (the training step, which uses batch
+        statistics) skips the folded moving-statistics scale/shift vectors; the next inference call packs them."""
+        if self._dirty or (fold and not self._folded):
+            self._want_fold = fold
             self._pack()
             self._dirty = False
+            self._folded = fold
 
 
 def _check_cubic_pow2(shape):

@@ -9,6 +9,7 @@ by the GLOBAL batch, and the gradients are summed across ranks by one bucketed a
 backend 'nccl'; gloo in the CPU tests of the bucketing logic) before Adam runs on every replica.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -207,12 +208,14 @@ class Trainer:
         L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), batch, side, cin, cout, self._dt(src), self._dt(g), L.ptr(ws),
                ws.numel(), _st())
 
-    def _conv(self, x, w_keras, B, side, cin, cout):
-        """Conv3D k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cin,cout]: the forward layers and the
-        data gradients of the transposed layers."""
+    def _conv(self, x, w_keras, B, side, cin, cout, packed=None):
+        """Conv3D k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cin,cout]: the forward layers (packed =
+        the engine's image of the same weights) and the data gradients of the transposed layers (packed here)."""
         dt, st = self.dt, _st()
-        wp = self._aempty(cout, 64 * cin)
-        L.call('vv_pack_conv_k4', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
+        wp = packed
+        if wp is None:
+            wp = self._aempty(cout, 64 * cin)
+            L.call('vv_pack_conv_k4', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
         y = self._aempty(B, side // 2, side // 2, side // 2, cout)
         if L.load().vv_conv3d_k4s2_direct_supported(side, cin, cout, dt):
             L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
@@ -221,18 +224,22 @@ class Trainer:
             L.call('vv_conv3d_k4s2_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
         return y
 
-    def _convT(self, x, w_keras, B, side, cin, cout):
+    def _convT(self, x, w_keras, B, side, cin, cout, packed=None, packed_frag=None):
         """Conv3DTranspose k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cout,cin]: the forward
-        transposed layers and the data gradients of the strided convolutions."""
+        transposed layers (packed / packed_frag = the engine's images) and the data gradients of the strided convolutions."""
         dt, st = self.dt, _st()
         y = self._aempty(B, 2 * side, 2 * side, 2 * side, cout)
-        if L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt):
-            wf = self._aempty(64 * cin * cout)
-            L.call('vv_pack_convT_k4s2_frag', L.ptr(w_keras), L.ptr(wf), cin, cout, st)
+        if L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT'):
+            wf = packed_frag
+            if wf is None:
+                wf = self._aempty(64 * cin * cout)
+                L.call('vv_pack_convT_k4s2_frag', L.ptr(w_keras), L.ptr(wf), cin, cout, st)
             L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wf), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
         else:
-            wp = self._aempty(8, cout, 8 * cin)
-            L.call('vv_pack_convT_k4s2', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
+            wp = packed
+            if wp is None:
+                wp = self._aempty(8, cout, 8 * cin)
+                L.call('vv_pack_convT_k4s2', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
             ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, cin, cout, dt))
             L.call('vv_convT3d_k4s2_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
         return y
@@ -240,8 +247,8 @@ class Trainer:
     # ------------------------------------------------------------------ one step
     def step(self, x, y, eps=None, drop_mask=None, drop_scale=1.0):
         """x, y: float32 CUDA [B,D,D,D,1].  Returns device tensors (loss_kl or None, stats [B,4], metrics [4])."""
-        self.enc.ensure_packed()
-        self.dec.ensure_packed()
+        self.enc.ensure_packed(fold=False)
+        self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
@@ -256,7 +263,7 @@ class Trainer:
         encoder owned by the caller.  Trains the decoder and returns (loss_kl, stats, metrics, d total / d enc_out) so the
         caller can continue the backward pass through its own encoder.  l2: coefficient of the decoder's kernel / bias
         regularisers when the caller's loss includes them."""
-        self.dec.ensure_packed()
+        self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
         overlap, self.overlap = self.overlap, self.overlap and l2 == 0      # the l2 terms are added before the cross-rank sum
         B = enc_out.shape[0]
@@ -278,8 +285,8 @@ class Trainer:
         graph to enc_out (continuing into the HIP encoder backward) and to whatever parameters latent_fn touched."""
         if self.var:
             raise ValueError('step_custom_latent expects a Trainer built with variational=False (the decoder input is z_input)')
-        self.enc.ensure_packed()
-        self.dec.ensure_packed()
+        self.enc.ensure_packed(fold=False)
+        self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)
@@ -304,7 +311,7 @@ class Trainer:
         h, bn = self._bn_fwd(c, B * side ** 3, fe[0], enc, 'bn0', act)
         ec.append(c); eh.append(h); ebn.append(bn)
         for i in range(1, len(fe) - 1):
-            c = self._conv(eh[-1], enc.params['conv%d/kernel' % i], B, side, fe[i - 1], fe[i])
+            c = self._conv(eh[-1], enc.params['conv%d/kernel' % i], B, side, fe[i - 1], fe[i], packed=enc.packed['w%d' % i])
             side //= 2
             h, bn = self._bn_fwd(c, B * side ** 3, fe[i], enc, 'bn%d' % i, act)
             ec.append(c); eh.append(h); ebn.append(bn)
@@ -339,7 +346,8 @@ class Trainer:
         dc_, dh_, dbn = [c_d1], [h_d1], [bn_d1]
         side = S
         for i in range(1, len(fd) - 1):
-            c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i])
+            c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i], packed=dec.packed['w%d' % i],
+                            packed_frag=dec.packed.get('wf%d' % i))
             side *= 2
             h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
             dc_.append(c); dh_.append(h); dbn.append(bn)

