@@ -37,38 +37,80 @@ __device__ __forceinline__ f32x4 ld4_rt(const void *p, long elem, int is_bf16) {
     return is_bf16 ? ld4(reinterpret_cast<const __bf16 *>(p) + elem, 0) : ld4(reinterpret_cast<const float *>(p) + elem, 0);
 }
 
+// Vector width of the BatchNorm sweeps: 16 bytes per lane and load (4 floats / 8 bf16).
+template <typename T> struct BnVec { static constexpr int V = sizeof(T) == 2 ? 8 : 4; };
+template <typename T>
+__device__ __forceinline__ void ldv(const T *p, long iv, float (&o)[BnVec<T>::V]) {
+    if constexpr (sizeof(T) == 4) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(p)[iv];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e];
+    } else {
+        const bf16x8 v = reinterpret_cast<const bf16x8 *>(p)[iv];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void stv(T *p, long iv, const float (&o)[BnVec<T>::V]) {
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<f32x4 *>(p)[iv] = f32x4{o[0], o[1], o[2], o[3]};
+    } else {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = static_cast<__bf16>(o[e]);
+        reinterpret_cast<bf16x8 *>(p)[iv] = v;
+    }
+}
+template <int V>
+__device__ __forceinline__ void ldp(const float *p, int c, float (&o)[V]) {      // V consecutive per-channel parameters
+#pragma unroll
+    for (int q = 0; q < V; q += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p + c + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[q + e] = v[e];
+    }
+}
+template <typename T>
+__device__ __forceinline__ float bn_act_grad(float u, int act) {                  // act'(u)
+    if (act == VV_ACT_ELU) return u > 0.f ? 1.f : (sizeof(T) == 4 ? expf(fminf(u, 0.f)) : __expf(fminf(u, 0.f)));
+    if (act == VV_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    if (act == VV_ACT_LRELU) return u > 0.f ? 1.f : 0.3f;
+    return 1.f;
+}
+
+// Per-block partial sums over a row range.  MODE 0: (sum x, sum x^2).  MODE 1: (sum du, sum du * xhat), du = dy * act'.
+// A thread owns V consecutive channels; 256 / (C / V) rows run in parallel, four rows per thread in flight.
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
                                                         float *__restrict__ partial, long R, int C, int rows_per_block, int act) {
-    __shared__ float red[2][256 * 4];
-    const int c4n = C >> 2;                  // float4 columns per row
+    constexpr int V = BnVec<T>::V;
+    __shared__ float red[2][256 * V];
+    const int cvn = C / V;                   // vector columns per row
     const int tid = threadIdx.x;
-    const int rows_par = 256 / c4n > 0 ? 256 / c4n : 1;   // rows handled in parallel (C <= 1024)
-    const int c4 = tid % c4n, rsub = tid / c4n;
+    const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;   // rows handled in parallel (C <= 256 V)
+    const int cv = tid % cvn, rsub = tid / cvn;
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    f32x4 sc = {1, 1, 1, 1}, sh = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, rs = {1, 1, 1, 1};
-    if (MODE == 1) {
-        sc = *reinterpret_cast<const f32x4 *>(scale + c4 * 4);
-        sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
-        mu = *reinterpret_cast<const f32x4 *>(mean + c4 * 4);
-        rs = *reinterpret_cast<const f32x4 *>(rstd + c4 * 4);
-    }
-    auto fold = [&](const f32x4 v, const f32x4 g) {
-        if (MODE == 0) {
-            s0 += v;
-            s1 += v * v;
-        } else {
+    float s0[V], s1[V], sc[V], sh[V], mu[V], rs[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = v[e] * sc[e] + sh[e];
-                float d = g[e];
-                if (act == VV_ACT_ELU) d *= (u > 0.f ? 1.f : (sizeof(T) == 4 ? expf(fminf(u, 0.f)) : __expf(fminf(u, 0.f))));
-                else if (act == VV_ACT_RELU) d = u > 0.f ? d : 0.f;
-                else if (act == VV_ACT_LRELU) d *= (u > 0.f ? 1.f : 0.3f);
+    for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; sc[e] = 1.f; sh[e] = 0.f; mu[e] = 0.f; rs[e] = 1.f; }
+    if (MODE == 1) {
+        ldp<V>(scale, cv * V, sc);
+        ldp<V>(shift, cv * V, sh);
+        ldp<V>(mean, cv * V, mu);
+        ldp<V>(rstd, cv * V, rs);
+    }
+    auto fold = [&](const float (&v)[V], const float (&g)[V]) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (MODE == 0) {
+                s0[e] += v[e];
+                s1[e] += v[e] * v[e];
+            } else {
+                const float d = g[e] * bn_act_grad<T>(v[e] * sc[e] + sh[e], act);
                 s0[e] += d;
                 s1[e] += d * ((v[e] - mu[e]) * rs[e]);
             }
@@ -78,27 +120,37 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x,
         long r = r0 + rsub;
         // four rows per trip: eight independent loads in flight per thread (the sweep is HBM-bound)
         for (; r + 3L * rows_par < r1; r += 4L * rows_par) {
-            f32x4 v[4], g[4];
+            float v[4][V], g[4][V];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[k] = ld4(x + (r + (long)k * rows_par) * C, c4);
-                g[k] = MODE == 1 ? ld4(dy + (r + (long)k * rows_par) * C, c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ldv<T>(x + (r + (long)k * rows_par) * C, cv, v[k]);
+                if (MODE == 1) ldv<T>(dy + (r + (long)k * rows_par) * C, cv, g[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) fold(v[k], g[k]);
         }
-        for (; r < r1; r += rows_par) fold(ld4(x + r * C, c4), MODE == 1 ? ld4(dy + r * C, c4) : f32x4{0.f, 0.f, 0.f, 0.f});
+        for (; r < r1; r += rows_par) {
+            float v[V], g[V];
+            ldv<T>(x + r * C, cv, v);
+            if (MODE == 1) ldv<T>(dy + r * C, cv, g);
+            fold(v, g);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][tid * 4 + e] = s0[e]; red[1][tid * 4 + e] = s1[e]; }
+    for (int e = 0; e < V; ++e) { red[0][tid * V + e] = s0[e]; red[1][tid * V + e] = s1[e]; }
     __syncthreads();
-    if (tid < c4n) {
-        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-        for (int k = 0; k < rows_par && k * c4n + tid < 256; ++k)
+    if (tid < cvn) {
+        float a[V], b[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] += red[0][(k * c4n + tid) * 4 + e]; b[e] += red[1][(k * c4n + tid) * 4 + e]; }
-        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 0) * C + tid * 4) = a;
-        *reinterpret_cast<f32x4 *>(partial + ((size_t)blockIdx.x * 2 + 1) * C + tid * 4) = b;
+        for (int e = 0; e < V; ++e) { a[e] = 0.f; b[e] = 0.f; }
+        for (int k = 0; k < rows_par && k * cvn + tid < 256; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { a[e] += red[0][(k * cvn + tid) * V + e]; b[e] += red[1][(k * cvn + tid) * V + e]; }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            partial[((size_t)blockIdx.x * 2 + 0) * C + tid * V + e] = a[e];
+            partial[((size_t)blockIdx.x * 2 + 1) * C + tid * V + e] = b[e];
+        }
     }
 }
 
@@ -160,18 +212,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     dgamma[c] = (float)ss;
 }
 
-// y = act(x*scale + shift)
+// y = act(x*scale + shift); nv = number of V-element vectors (C % V == 0)
 template <typename T>
 __global__ void bn_act_fwd_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
-                                  T *__restrict__ y, long n4, int C, int act) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 v = ld4(x, i);
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
-        f32x4 o;
+                                  T *__restrict__ y, long nv, int C, int act) {
+    constexpr int V = BnVec<T>::V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * V) % C);
+        float v[V], sc[V], sh[V], o[V];
+        ldv<T>(x, i, v);
+        ldp<V>(scale, c, sc);
+        ldp<V>(shift, c, sh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = vv_apply_act(v[e] * sc[e] + sh[e], act);
-        st4(y, i, o);
+        for (int e = 0; e < V; ++e) o[e] = vv_apply_act(v[e] * sc[e] + sh[e], act);
+        stv<T>(y, i, o);
     }
 }
 
@@ -180,26 +234,26 @@ template <typename T>
 __global__ void bn_act_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ scale,
                                   const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
                                   const float *__restrict__ dgamma, const float *__restrict__ dbeta, T *__restrict__ dx,
-                                  long n4, int C, float invR, int act) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 v = ld4(x, i), g = ld4(dy, i);
-        // the six per-channel vectors as float4 (one 16-byte load each instead of 24 scalar loads per quad)
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c), sh = *reinterpret_cast<const f32x4 *>(shift + c);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + c), rs = *reinterpret_cast<const f32x4 *>(rstd + c);
-        const f32x4 dg = *reinterpret_cast<const f32x4 *>(dgamma + c), db = *reinterpret_cast<const f32x4 *>(dbeta + c);
-        f32x4 o;
+                                  long nv, int C, float invR, int act) {
+    constexpr int V = BnVec<T>::V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * V) % C);
+        float v[V], g[V], sc[V], sh[V], mu[V], rs[V], dg[V], db[V], o[V];
+        ldv<T>(x, i, v);
+        ldv<T>(dy, i, g);
+        ldp<V>(scale, c, sc);
+        ldp<V>(shift, c, sh);
+        ldp<V>(mean, c, mu);
+        ldp<V>(rstd, c, rs);
+        ldp<V>(dgamma, c, dg);
+        ldp<V>(dbeta, c, db);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u = v[e] * sc[e] + sh[e];
-            float d = g[e];
-            if (act == VV_ACT_ELU) d *= (u > 0.f ? 1.f : (sizeof(T) == 4 ? expf(fminf(u, 0.f)) : __expf(fminf(u, 0.f))));
-            else if (act == VV_ACT_RELU) d = u > 0.f ? d : 0.f;
-            else if (act == VV_ACT_LRELU) d *= (u > 0.f ? 1.f : 0.3f);
+        for (int e = 0; e < V; ++e) {
+            const float d = g[e] * bn_act_grad<T>(v[e] * sc[e] + sh[e], act);
             const float xh = (v[e] - mu[e]) * rs[e];
             o[e] = sc[e] * (d - db[e] * invR - xh * dg[e] * invR);
         }
-        st4(dx, i, o);
+        stv<T>(dx, i, o);
     }
 }
 
@@ -328,7 +382,8 @@ struct WgradBArgs {
     unsigned a_bytes, g_bytes;
 };
 
-template <int AMODE>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0
+template <int AMODE>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0;
+                          // 2: A[r][t] = src[b, 2o-1+t] of a single-channel float32 grid (M = 64), built in registers
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) {
     constexpr int BM = 128, BN = 128, BR = 64, OPB = BR * 128 * 2;        // one operand chunk: 16 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];           // [2 stages][A | G]
@@ -369,10 +424,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
                 if (ncol < a.N) vg = (unsigned)((r * a.N + ncol + pch * 8) * 2);
             }
             const unsigned dst = lds0 + st * (2 * OPB) + cb * 4096 + rg * 1024;
-            vv_dma16(rsa, va, dst);
+            if (AMODE != 2) vv_dma16(rsa, va, dst);
             vv_dma16(rsg, vg, dst + OPB);
         }
     };
+    // AMODE 2: thread = (chunk row tid >> 2, tap plane td = tid & 3) owns 16 taps (th, tw) = 32 bytes of the row.  The
+    // occupancy is loaded one chunk ahead (four 16-byte loads of the 4-voxel run 2 ow - 1 .. 2 ow + 2, read at a shifted
+    // base on the two grid edges so that no load leaves the row), converted and written after the MFMAs of the chunk.
+    const float *srcf = reinterpret_cast<const float *>(a.A);
+    f32x4 xr[4];
+    int xsh = 0;
+    auto load_x = [&](long rc) {
+        const long r = rc + (tid >> 2);
+        const int td = tid & 3;
+        const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
+        const long b = r >> (3 * lo);
+        const int id = 2 * od - 1 + td, iw0 = 2 * ow - 1;
+        xsh = iw0 < 0 ? 1 : (iw0 + 3 >= n ? -1 : 0);
+#pragma unroll
+        for (int th = 0; th < 4; ++th) {
+            const int ih = 2 * oh - 1 + th;
+            const bool ok = r < r_end && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n;
+            xr[th] = ok ? *reinterpret_cast<const f32x4 *>(srcf + ((((b << li) + id << li) + ih) << li) + iw0 + xsh) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_x = [&](int st) {
+        const int row = tid >> 2, td = tid & 3;
+        bf16x8 o[2];
+#pragma unroll
+        for (int th = 0; th < 4; ++th) {
+            const f32x4 l = xr[th];
+            const f32x4 v = xsh == 0 ? l : (xsh > 0 ? f32x4{0.f, l[0], l[1], l[2]} : f32x4{l[1], l[2], l[3], 0.f});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[th >> 1][(th & 1) * 4 + e] = static_cast<__bf16>(v[e]);
+        }
+        char *dst = smem + st * (2 * OPB) + (td >> 1) * 4096 + row * 64 + (td & 1) * 32;
+        *reinterpret_cast<bf16x8 *>(dst) = o[0];
+        *reinterpret_cast<bf16x8 *>(dst + 16) = o[1];
+    };
+    if (AMODE == 2) {                                      // taps 64..127 of the 128-wide tile do not exist: column blocks 2, 3 stay zero
+        const bf16x8 z = {};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8 *>(smem + (tid >> 7) * (2 * OPB) + 8192 + ((tid & 127) * 4 + q) * 16) = z;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -395,11 +489,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
 
     long rc = r_begin;
     int st = 0;
-    if (rc < r_end) stage(rc, 0);
+    if (rc < r_end) {
+        if (AMODE == 2) { load_x(rc); store_x(0); }
+        stage(rc, 0);
+    }
     for (; rc < r_end; rc += BR, st ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // chunk landed for everyone; previous chunk's reads are done
-        if (rc + BR < r_end) stage(rc + BR, st ^ 1);
+        const bool more = rc + BR < r_end;
+        if (more) {
+            if (AMODE == 2) load_x(rc + BR);
+            stage(rc + BR, st ^ 1);
+        }
         const unsigned sa = lds0 + st * (2 * OPB), sg = sa + OPB;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -414,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);   // D[m][n]
         }
+        if (AMODE == 2 && more) store_x(st ^ 1);
     }
     const int fr = lane & 31, fh = lane >> 5;
     float *slab = a.slabs + (size_t)blockIdx.y * a.M * a.N;
@@ -429,32 +531,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
                 if (m < a.M) slab[(size_t)m * a.N + nn] = acc[i][j][q];
             }
         }
-}
-
-// im2col of a single-channel grid for the k4 s2 SAME window: out[(b,o)][t] = src[b, 2o-1+t] (0 in the padding), bf16.
-// Feeds the bf16 weight-gradient kernel for the two Cin = 1 layers (first conv: src = x; last transposed conv: src =
-// dL/dlogit), whose float32 gather form spent 0.4 ms per layer on scalar tap loads.  One thread = 8 taps (td, th pair,
-// tw 0..3) of one row = one 16-byte store.
-__global__ void im2col_c1_kernel(const float *__restrict__ src, __bf16 *__restrict__ out, int din_log2, long rows) {
-    const int li = din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
-    const long total = rows * 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i >> 3;
-        const int gq = (int)(i & 7), td = gq >> 1, th0 = (gq & 1) * 2;
-        const int ow = (int)(r & omsk), oh = (int)((r >> lo) & omsk), od = (int)((r >> (2 * lo)) & omsk);
-        const long b = r >> (3 * lo);
-        const int id = 2 * od - 1 + td, iw0 = 2 * ow - 1;
-        bf16x8 o;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int ih = 2 * oh - 1 + th0 + rr;
-            const bool okr = (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n;
-            const float *p = src + ((((b << li) + id) << li) + ih << li) + iw0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[rr * 4 + e] = static_cast<__bf16>((okr && (unsigned)(iw0 + e) < (unsigned)n) ? p[e] : 0.f);
-        }
-        reinterpret_cast<bf16x8 *>(out)[i] = o;
-    }
 }
 
 __global__ void wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, long n, int splits, float alpha,
@@ -654,9 +730,16 @@ inline int grid_1d(long n) {
 
 // Row blocks of the two BatchNorm sweeps: 256 rows per block on the long layers (at most 1024 blocks), but never fewer
 // blocks than keep ~16 rows per block -- a 2048-row x 512-channel layer is 128 blocks, not 8.
-inline int bn_blocks(long R, int C) {
-    const int c4n = C >> 2;
-    const int rows_par = 256 / c4n > 0 ? 256 / c4n : 1;
+// A thread owns V consecutive channels (4 floats / 8 bf16) and a workgroup spans whole rows: C % V == 0, C / V <= 256
+inline bool bn_shape_ok(long rows, int channels, int dtype) {
+    const int V = dtype == VV_BF16 ? 8 : 4;
+    if (rows <= 0 || channels <= 0 || channels % V || channels / V > 256) return false;
+    return channels / V >= 64 || 256 % (channels / V) == 0;
+}
+
+inline int bn_blocks(long R, int C, int V = 4) {
+    const int cvn = C / V;
+    const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
     long per = 8L * rows_par;                   // two trips of the 4-rows-in-flight loop
     if (per < 16) per = 16;
     if (per > 256) per = 256;
@@ -673,10 +756,10 @@ VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const fl
                                 float *moving_mean, float *moving_var, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !gamma || !beta || !mean || !var || !rstd || !scale || !shift) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
+    if (!bn_shape_ok(rows, channels, dtype)) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nb = bn_blocks(rows, channels);
+    const int nb = bn_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);     // <= the float32 count the workspace is sized for
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
     if (dtype == VV_BF16)
@@ -694,8 +777,8 @@ VV_EXPORT int vv_bn_act_fwd(const void *x, const float *scale, const float *shif
                             int dtype, void *stream) {
     if (!x || !scale || !shift || !y) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (rows <= 0 || channels <= 0 || channels % 4) return VV_ERR_SHAPE;
-    const long n4 = rows * channels / 4;
+    if (rows <= 0 || channels <= 0 || channels % (dtype == VV_BF16 ? 8 : 4)) return VV_ERR_SHAPE;
+    const long n4 = rows * channels / (dtype == VV_BF16 ? 8 : 4);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == VV_BF16)
         VV_LAUNCH(bn_act_fwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), scale, shift,
@@ -711,13 +794,13 @@ VV_EXPORT int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, c
                             int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !dy || !scale || !shift || !mean || !rstd || !dgamma || !dbeta || !dx) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (rows <= 0 || channels <= 0 || channels % 4 || channels > 1024 || (channels < 256 && 256 % (channels / 4))) return VV_ERR_SHAPE;
+    if (!bn_shape_ok(rows, channels, dtype)) return VV_ERR_SHAPE;
     if (!workspace || workspace_bytes < vv_bn_workspace_bytes(rows, channels)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nb = bn_blocks(rows, channels);
+    const int nb = bn_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);     // <= the float32 count the workspace is sized for
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
-    const long n4 = rows * channels / 4;
+    const long n4 = rows * channels / (dtype == VV_BF16 ? 8 : 4);
     if (dtype == VV_BF16) {
         const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *dyb = reinterpret_cast<const __bf16 *>(dy);
         VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
@@ -806,8 +889,7 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
 
 VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) {
     const size_t a = wgrad_plan(rows, m, n).ws;     // the caller need not know which kernel runs
-    size_t b = wgrad_plan_bf16(rows, m, n).ws;
-    if (m == 64) b = ((b + 255) & ~(size_t)255) + (size_t)rows * 64 * 2;   // single-channel layers: bf16 im2col rows behind the slabs
+    const size_t b = wgrad_plan_bf16(rows, m, n).ws;
     return a > b ? a : b;
 }
 
@@ -846,14 +928,12 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
                       (unsigned)(src_elems * 2), (unsigned)((size_t)rows * cout * 2)};
         return launch_wgrad_bf16<1>(wb, pb, dw, st);
     }
-    if (cin == 1 && g_dtype == VV_BF16 && cout % 32 == 0 && (size_t)rows * 64 * 2 < 0xFFFFFFF0ull && vv_aligned16(g) && !getenv("VV_WGRAD_F32")) {
-        // single input channel: materialise the im2col rows in bf16 behind the slabs, then the dense bf16 kernel
+    if (cin == 1 && side >= 4 && g_dtype == VV_BF16 && cout % 32 == 0 && (size_t)rows * cout * 2 < 0xFFFFFFF0ull && vv_aligned16(g) && !getenv("VV_WGRAD_F32")) {
+        // single input channel: the 64-tap rows are built from the float32 grid inside the bf16 kernel's staging
         const WgradPlan pb = wgrad_plan_bf16(rows, 64, cout);
-        __bf16 *col = reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(workspace) + ((pb.ws + 255) & ~(size_t)255));
-        VV_LAUNCH(im2col_c1_kernel, dim3(grid_1d(rows * 8)), dim3(256), 0, st, reinterpret_cast<const float *>(src), col, vv_log2(side), rows);
-        WgradBArgs wb{col, g, reinterpret_cast<float *>(workspace), rows, 64, cout, 64, 0, 0, pb.rps, (unsigned)((size_t)rows * 64 * 2),
+        WgradBArgs wb{src, g, reinterpret_cast<float *>(workspace), rows, 64, cout, 0, vv_log2(side), 1, pb.rps, 0u,
                       (unsigned)((size_t)rows * cout * 2)};
-        return launch_wgrad_bf16<0>(wb, pb, dw, st);
+        return launch_wgrad_bf16<2>(wb, pb, dw, st);
     }
     const WgradPlan p = wgrad_plan(rows, m, cout);
     WgradArgs w{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, p.rps, src_dtype == VV_BF16,

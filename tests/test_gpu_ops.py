@@ -366,3 +366,71 @@ def test_wgrad_kernels(L, adt, gdt, monkeypatch):
                ws.numel(), _st())
         torch.cuda.synchronize()
         assert (out - out2).abs().max().item() <= 2e-5 * refmax
+
+
+@pytest.mark.parametrize('dtname', ['f32', 'bf16'])
+@pytest.mark.parametrize('rows,C', [(4096, 64), (2048, 512), (777, 128), (5, 256), (300, 1024), (20000, 64)])
+def test_batchnorm_train_ops(L, dtname, rows, C):
+    """Training-mode BatchNorm + activation: batch statistics (biased variance, Keras momentum update), forward and the
+    three-output backward, against float64 numpy (BatchNormalization semantics as restated in oracle/torch_oracle.py)."""
+    rng = np.random.default_rng(rows + C)
+    dt, tdt = L.DTYPES[dtname], (torch.float32 if dtname == 'f32' else torch.bfloat16)
+    x = (rng.standard_normal((rows, C)) * rng.uniform(0.5, 2.0, C) + rng.normal(0, 1, C)).astype(np.float32)
+    dy = rng.standard_normal((rows, C)).astype(np.float32)
+    if dtname == 'bf16':
+        x, dy = _bf16_round(x), _bf16_round(dy)
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 0.3, C).astype(np.float32)
+    mm0, mv0 = rng.normal(0, 1, C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
+    eps, mom, act = 1e-3, 0.99, 1
+    x64 = x.astype(np.float64)
+    mean, var = x64.mean(0), x64.var(0)
+    rstd = 1.0 / np.sqrt(var + eps)
+    scale, shift = gamma * rstd, beta - mean * gamma * rstd
+    xd, dyd = _dev(x, tdt), _dev(dy, tdt)
+    gd, bd, mmd, mvd = _dev(gamma), _dev(beta), _dev(mm0), _dev(mv0)
+    o = {n: torch.empty(C, dtype=torch.float32, device=DEV) for n in ('mean', 'var', 'rstd', 'scale', 'shift', 'dgamma', 'dbeta')}
+    nb = L.load().vv_bn_workspace_bytes(rows, C)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=DEV)
+    L.call('vv_bn_train_stats', L.ptr(xd), rows, C, L.ptr(gd), L.ptr(bd), eps, mom, L.ptr(o['mean']), L.ptr(o['var']), L.ptr(o['rstd']),
+           L.ptr(o['scale']), L.ptr(o['shift']), L.ptr(mmd), L.ptr(mvd), dt, L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    for name, ref in (('mean', mean), ('var', var), ('rstd', rstd), ('scale', scale), ('shift', shift)):
+        got = o[name].cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), name
+    assert np.abs(mmd.cpu().numpy() - (mm0 * mom + mean * (1 - mom))).max() <= 1e-5
+    assert np.abs(mvd.cpu().numpy() - (mv0 * mom + var * (1 - mom))).max() <= 1e-5
+    # forward / backward with the device's own statistics
+    sc, sh, mu, rs = (o[n].cpu().numpy().astype(np.float64) for n in ('scale', 'shift', 'mean', 'rstd'))
+    u = x64 * sc + sh
+    y = torch.empty_like(xd)
+    L.call('vv_bn_act_fwd', L.ptr(xd), L.ptr(o['scale']), L.ptr(o['shift']), L.ptr(y), rows, C, act, dt, _st())
+    torch.cuda.synchronize()
+    _check(y, no.activation(u, 'elu'), dtname, 'bn_act_fwd')
+    du = dy.astype(np.float64) * np.where(u > 0, 1.0, np.exp(np.minimum(u, 0)))
+    xh = (x64 - mu) * rs
+    dbeta, dgamma = du.sum(0), (du * xh).sum(0)
+    dx_ref = sc * (du - dbeta / rows - xh * dgamma / rows)
+    dx = torch.empty_like(xd)
+    L.call('vv_bn_act_bwd', L.ptr(xd), L.ptr(dyd), L.ptr(o['scale']), L.ptr(o['shift']), L.ptr(o['mean']), L.ptr(o['rstd']),
+           L.ptr(o['dgamma']), L.ptr(o['dbeta']), L.ptr(dx), rows, C, act, dt, L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtname == 'f32' else 2e-3       # bf16 mode evaluates exp with the hardware approximation; sums are float32
+    assert np.abs(o['dbeta'].cpu().numpy() - dbeta).max() <= tol * max(1.0, np.abs(dbeta).max())
+    assert np.abs(o['dgamma'].cpu().numpy() - dgamma).max() <= tol * max(1.0, np.abs(dgamma).max())
+    _check(dx, dx_ref, dtname, 'bn_act_bwd')
+    if dtname == 'bf16':
+        assert L.load().vv_bn_act_fwd(L.ptr(xd), L.ptr(o['scale']), L.ptr(o['shift']), L.ptr(y), rows, 12, act, dt, _st()) == -2      # VV_ERR_SHAPE: bf16 rows are swept 8 channels per lane
+
+
+@pytest.mark.parametrize('dtname', ['f32', 'bf16'])
+@pytest.mark.parametrize('rows,C', [(256, 256), (3, 64), (1000, 40)])
+def test_colsum(L, dtname, rows, C):
+    rng = np.random.default_rng(rows)
+    tdt = torch.float32 if dtname == 'f32' else torch.bfloat16
+    x = rng.standard_normal((rows, C)).astype(np.float32)
+    if dtname == 'bf16':
+        x = _bf16_round(x)
+    out = torch.empty(C, dtype=torch.float32, device=DEV)
+    L.call('vv_colsum', L.ptr(_dev(x, tdt)), L.ptr(out), rows, C, L.DTYPES[dtname], _st())
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - x.astype(np.float64).sum(0)).max() <= 1e-4
