@@ -839,7 +839,10 @@ WgradPlan wgrad_plan_bf16(long R, int M, int N) {
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     long chunks = (R + 63) / 64;
     long splits = 1;
-    while (tiles * splits < 512 && splits * 2 <= chunks && splits < 256) splits *= 2;
+    // one or two tiles (the single-channel layers, M = N = 64): the kernel is a latency-bound stream over the rows, so
+    // four workgroups per CU's worth of splits instead of two
+    const long want = tiles <= 2 ? 1024 : 512;
+    while (tiles * splits < want && splits * 2 <= chunks && splits < want) splits *= 2;
     p.rps = (int)(((chunks + splits - 1) / splits) * 64);
     p.splits = (int)((R + p.rps - 1) / p.rps);
     p.ws = (size_t)p.splits * M * N * sizeof(float);
