@@ -93,3 +93,9 @@ __device__ __forceinline__ float vv_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// wgrad_phase.hip (internal): phase-form weight gradient of the stride-2 layers; the caller sums *splits slabs.
+bool vv_wgrad_phase_ok(const void *src, const void *g, int batch, int side, int cin, int cout);
+size_t vv_wgrad_phase_ws(long rows, int cin, int cout);
+void vv_wgrad_phase_launch(const void *src, const void *g, float *slabs, int batch, int side, int cin, int cout, int *splits,
+                           hipStream_t st);

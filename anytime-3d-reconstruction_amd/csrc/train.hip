@@ -892,7 +892,9 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
 
 VV_EXPORT size_t vv_wgrad_workspace_bytes(long rows, int m, int n) {
     const size_t a = wgrad_plan(rows, m, n).ws;     // the caller need not know which kernel runs
-    const size_t b = wgrad_plan_bf16(rows, m, n).ws;
+    size_t b = wgrad_plan_bf16(rows, m, n).ws;
+    const size_t c = m % 4096 == 0 ? vv_wgrad_phase_ws(rows, m / 64, n) : 0;     // conv layers: the phase kernel's slabs
+    if (c > b) b = c;
     return a > b ? a : b;
 }
 
@@ -925,6 +927,12 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
     if (!workspace || workspace_bytes < vv_wgrad_workspace_bytes(rows, m, cout)) return VV_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t src_elems = (size_t)batch * side * side * side * cin;
+    if (cin != 1 && src_dtype == VV_BF16 && g_dtype == VV_BF16 && vv_wgrad_phase_ok(src, g, batch, side, cin, cout)) {
+        int splits = 0;
+        vv_wgrad_phase_launch(src, g, reinterpret_cast<float *>(workspace), batch, side, cin, cout, &splits, st);
+        launch_wgrad_reduce(reinterpret_cast<const float *>(workspace), dw, (long)m * cout, splits, 1.f, 0, st);
+        return vv_launch_status();
+    }
     if (cin != 1 && src_dtype == VV_BF16 && g_dtype == VV_BF16 && wgrad_bf16_ok(src, g, rows, m, cout, 0, cin, 1, src_elems)) {
         const WgradPlan pb = wgrad_plan_bf16(rows, m, cout);
         WgradBArgs wb{src, g, reinterpret_cast<float *>(workspace), rows, m, cout, 0, vv_log2(side), cin, pb.rps,

@@ -434,3 +434,30 @@ def test_colsum(L, dtname, rows, C):
     L.call('vv_colsum', L.ptr(_dev(x, tdt)), L.ptr(out), rows, C, L.DTYPES[dtname], _st())
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - x.astype(np.float64).sum(0)).max() <= 1e-4
+
+
+@pytest.mark.parametrize('B,side,cin,cout', [(2, 16, 64, 128), (5, 16, 64, 128), (16, 8, 128, 256), (17, 8, 64, 128), (1, 32, 64, 128),
+                                             (4, 16, 128, 128)])
+def test_wgrad_conv_phase_form(L, B, side, cin, cout, monkeypatch):
+    """Phase-form weight gradient (wgrad_phase.hip: bf16, cin % 64 == 0, cout % 128 == 0, output side 4 / 8 / 16): one
+    staged parity sub-grid tile feeds the 8 taps of the parity.  Against the float64 definition and against the
+    reduction-GEMM kernel on the same bf16 operands (the two differ by float32 summation order only); odd batches leave
+    the last box half empty."""
+    rng = np.random.default_rng(B * 100 + side)
+    src = _bf16_round(rng.standard_normal((B, side, side, side, cin)).astype(np.float32))
+    o = side // 2
+    g = _bf16_round(rng.standard_normal((B, o, o, o, cout)).astype(np.float32))
+    ref = _wgrad_conv_ref(src.astype(np.float64), g.astype(np.float64))
+    sd, gd = _dev(src, torch.bfloat16), _dev(g, torch.bfloat16)
+    ws = torch.empty(L.load().vv_wgrad_workspace_bytes(B * o ** 3, 64 * cin, cout), dtype=torch.uint8, device=DEV)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('VV_NO_WGRAD_PHASE', '1')
+        out = torch.full((4, 4, 4, cin, cout), 7.0, dtype=torch.float32, device=DEV)
+        L.call('vv_wgrad_conv_k4s2', L.ptr(sd), L.ptr(gd), L.ptr(out), B, side, cin, cout, L.VV_BF16, L.VV_BF16, L.ptr(ws), ws.numel(), _st())
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        err = np.abs(outs[-1] - ref).max()
+        assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('phase off' if off else 'phase on', err)
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * np.abs(ref).max() + 1e-5
