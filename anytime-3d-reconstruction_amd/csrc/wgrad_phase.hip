@@ -75,34 +75,52 @@ __global__ __launch_bounds__(512, 1) void wgrad_phase_kernel(const WgPhaseArgs a
     const int box0 = split * a.boxes_per_split;
     const int box1 = box0 + a.boxes_per_split < a.nboxes ? box0 + a.boxes_per_split : a.nboxes;
 
-    // ---- staging: piece = 16 rows x 64 B of one channel block; pieces 0 .. 2 NG - 1 the tile, then 32 of the g box
-    constexpr int NPX = 2 * G::NG, NP = NPX + 32, NIT = (NP + 7) / 8;
+    // ---- staging: piece = 16 rows x 64 B of one channel block; pieces 0 .. 2 NG - 1 the tile, then 32 of the g box; wave w
+    // issues pieces w, w + 8, ...  Everything about a lane's 16 bytes that does not depend on the box is computed once:
+    // the byte offset relative to the box origin and the tile cell (for the padding test), so that a box costs a dozen
+    // integer operations per piece instead of the divisions by 9 / 81 (the first version spent more VALU time on these
+    // than the matrix pipe spent on the box).
+    constexpr int NPX = 2 * G::NG, NITX = NPX / 8, NITG = 4;
+    static_assert(NPX % 8 == 0, "tile pieces split evenly over the waves");
     const int prow = lane >> 2, pch = lane & 3;
+    unsigned xrel[NITX];
+    unsigned xcell[NITX];                                                  // zd | jh << 8 | jw << 16 | sample << 24, bit 31: past the tile
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) {
+        const int id = it * 8 + wave, cbx = id / G::NG, grp = id - cbx * G::NG;
+        const int j = grp * 16 + prow;
+        const int jw = j % G::TW, jh = (j / G::TW) % G::TH, zd = (j / (G::TW * G::TH)) % G::TD, sl = j / (G::TW * G::TH * G::TD);
+        xrel[it] = (unsigned)((((((long)sl << li) + 2 * zd << li) + 2 * jh << li) + 2 * jw) * a.cin + cbx * 32 + pch * 8) * 2;
+        xcell[it] = (unsigned)zd | (unsigned)jh << 8 | (unsigned)jw << 16 | (unsigned)sl << 24 | (j < G::ROWS ? 0u : 0x80000000u);
+    }
+    unsigned grel[NITG];
+#pragma unroll
+    for (int it = 0; it < NITG; ++it) {
+        const int gid = it * 8 + wave, cbg = gid >> 3, grp = gid & 7;
+        grel[it] = (unsigned)(((grp * 16 + prow) * a.cout + cob * 128 + cbg * 32 + pch * 8) * 2);
+    }
     auto stage = [&](int box, int st) {
         const long r0 = (long)box * 128;
-        const int ow0 = 0;                                                 // boxes span whole rows
-        const int oh0 = (int)((r0 >> LS) & (G::S - 1)), od0 = (int)((r0 >> (2 * LS)) & (G::S - 1));
+        const int oh0 = (int)((r0 >> LS) & (G::S - 1)), od0 = (int)((r0 >> (2 * LS)) & (G::S - 1));   // boxes span whole rows: ow0 = 0
         const int b0 = (int)(r0 >> (3 * LS));
+        const int d0 = 2 * od0 - 1 + rd, h0 = 2 * oh0 - 1 + rh, w0 = rw - 1;                           // source cell of tile cell (0,0,0)
+        const unsigned xbase = (unsigned)((((((long)b0 << li) + d0 << li) + h0 << li) + w0) * a.cin + cib * 64) * 2;
         const unsigned sbase = lds0 + st * G::STAGE;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int id = it * 8 + wave;
-            if (id < NPX) {
-                const int cbx = id / G::NG, grp = id - cbx * G::NG;
-                const int j = grp * 16 + prow;
-                const int jw = j % G::TW, jh = (j / G::TW) % G::TH, zd = (j / (G::TW * G::TH)) % G::TD, sl = j / (G::TW * G::TH * G::TD);
-                const int b = b0 + sl;
-                const int id_ = 2 * (od0 + zd) - 1 + rd, ih = 2 * (oh0 + jh) - 1 + rh, iw = 2 * (ow0 + jw) - 1 + rw;
-                unsigned vo = 0xFFFFFFF0u;
-                if (j < G::ROWS && b < a.batch && (unsigned)id_ < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n)
-                    vo = (unsigned)(((((((long)b << li) + id_ << li) + ih << li) + iw) * a.cin + cib * 64 + cbx * 32 + pch * 8) * 2);
-                vv_dma16(rss, vo, sbase + cbx * G::XCB + grp * 1024);
-            } else if (id < NP) {
-                const int gid = id - NPX, cbg = gid >> 3, grp = gid & 7;
-                const long r = r0 + grp * 16 + prow;
-                const unsigned vo = r < a.rows ? (unsigned)((r * a.cout + cob * 128 + cbg * 32 + pch * 8) * 2) : 0xFFFFFFF0u;
-                vv_dma16(rsg, vo, sbase + 2 * G::XCB + cbg * 8192 + grp * 1024);
-            }
+        for (int it = 0; it < NITX; ++it) {
+            const int id = it * 8 + wave, cbx = id / G::NG, grp = id - cbx * G::NG;
+            const unsigned c = xcell[it];
+            const int id_ = d0 + 2 * (int)(c & 255), ih = h0 + 2 * (int)((c >> 8) & 255), iw = w0 + 2 * (int)((c >> 16) & 255);
+            const bool ok = (int)c >= 0 && b0 + (int)((c >> 24) & 127) < a.batch && (unsigned)id_ < (unsigned)n && (unsigned)ih < (unsigned)n &&
+                            (unsigned)iw < (unsigned)n;
+            vv_dma16(rss, ok ? xbase + xrel[it] : 0xFFFFFFF0u, sbase + cbx * G::XCB + grp * 1024);
+        }
+        const unsigned gbase = (unsigned)(r0 * a.cout * 2);
+        const int rleft = (int)(a.rows - r0 < 128 ? a.rows - r0 : 128);                                // rows of the box that exist
+#pragma unroll
+        for (int it = 0; it < NITG; ++it) {
+            const int gid = it * 8 + wave, cbg = gid >> 3, grp = gid & 7;
+            vv_dma16(rsg, grp * 16 + prow < rleft ? gbase + grel[it] : 0xFFFFFFF0u, sbase + 2 * G::XCB + cbg * 8192 + grp * 1024);
         }
     };
 
