@@ -604,7 +604,11 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     const long tiles = (long)((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn) * p.nparity;
     static const long target = getenv("VV_SPLIT_TARGET") ? atol(getenv("VV_SPLIT_TARGET")) : 512;
     int split = 1;
-    while (tiles * split < target && split * 2 <= nchunks / 8 && split < 64) split *= 2;
+    // at least 8 chunks per share -- 4 when the tile grid is a handful of workgroups (the Dense-shaped layers at batch
+    // 256: 2 tiles x K = 4096 ran as 8 workgroups of 16 dependent chunks, a latency chain of 18 us)
+    static const int min_chunks_small = getenv("VV_SPLIT_MINCHUNKS") ? atoi(getenv("VV_SPLIT_MINCHUNKS")) : 4;
+    const int min_chunks = tiles <= 8 ? min_chunks_small : 8;
+    while (tiles * split < target && split * 2 <= nchunks / min_chunks && split < 64) split *= 2;
     // The first factor of two is taken INSIDE the workgroup (two 4-wave halves on alternate chunks, accumulators handed
     // over through LDS): same waves per CU, half the slabs -- or none, and then no reduce pass at all.
     static const bool no_kh = getenv("VV_NO_KHALVES") != nullptr;
