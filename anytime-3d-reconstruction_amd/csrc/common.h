@@ -47,7 +47,7 @@ static inline int vv_log2(int v) {
     return l;
 }
 static inline bool vv_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static inline size_t vv_dtype_size(int dt) { return dt == VV_BF16 ? 2 : 4; }
+static inline size_t vv_dtype_size(int dt) { return dt == VV_BF16 ? 2 : (dt == VV_FP8 ? 1 : 4); }
 // hipGetLastError() is per-thread and may hold a stale error from the host framework: clear it, then launch.
 #define VV_LAUNCH(...)            \
     do {                          \
@@ -83,10 +83,28 @@ __device__ __forceinline__ float vv_apply_act_fast(float v, int act) {
     }
 }
 
+// OCP e4m3fn storage (gfx950's fp8; not MI300's fnuz).  Conversions saturate at +-448 by hand: the hardware convert maps
+// larger magnitudes to NaN.
+struct vv_fp8 { unsigned char v; };
+__device__ __forceinline__ unsigned vv_pack_fp8x4(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    return (unsigned)w;
+}
+__device__ __forceinline__ unsigned char vv_to_fp8(float v) {
+    v = fminf(fmaxf(v, -448.f), 448.f);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xFF);
+}
+__device__ __forceinline__ float vv_from_fp8(unsigned char b) { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0); }
+
 __device__ __forceinline__ float vv_load_f32(const float *p, size_t i) { return p[i]; }
 __device__ __forceinline__ float vv_load_f32(const __bf16 *p, size_t i) { return static_cast<float>(p[i]); }
 __device__ __forceinline__ void vv_store(float *p, size_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void vv_store(__bf16 *p, size_t i, float v) { p[i] = static_cast<__bf16>(v); }
+__device__ __forceinline__ void vv_store(vv_fp8 *p, size_t i, float v) { p[i].v = vv_to_fp8(v); }
+__device__ __forceinline__ float vv_load_f32(const vv_fp8 *p, size_t i) { return vv_from_fp8(p[i].v); }
 
 __device__ __forceinline__ float vv_wave_sum(float v) {
 #pragma unroll

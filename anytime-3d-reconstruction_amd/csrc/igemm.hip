@@ -46,7 +46,7 @@ struct IgemmArgs {
     int nchunks;       // K / BK
     int chunks_per_split;
     int act;
-    int out_bf16;      // output element type (1 bf16, 0 f32)
+    int out_kind;      // output element type: 0 bf16, 1 f32, 3 fp8 (e4m3fn)
     int batch;         // samples (conv modes)
     unsigned a_bytes, w_bytes;  // operand sizes for the buffer descriptors (out-of-range lanes read zeros)
     int nsplit, nparity;  // split-K shares and output-parity panels (both folded into the 1-D grid)
@@ -60,6 +60,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB +
 template <typename T> struct Elt;
 template <> struct Elt<float> { static constexpr int BK = 32; };
 template <> struct Elt<__bf16> { static constexpr int BK = 64; };
+template <> struct Elt<vv_fp8> { static constexpr int BK = 128; };
 
 // Per-thread description of one A row it stages.
 struct RowCtx {
@@ -171,6 +172,17 @@ template <>
 __device__ __forceinline__ void mma_step<__bf16>(const uint4 &a, const uint4 &b, f32x16 &acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&a),
                                                   *reinterpret_cast<const bf16x8 *>(&b), acc, 0, 0, 0);
+}
+// fp8: the 16-byte fragment is two 8-byte k-groups; v_mfma_f32_32x32x16_fp8_fp8 takes 8 bytes per lane (lane half h =
+// k 8h..8h+7 of its 16), so the low and the high words of both operands go through one MFMA each -- the same fixed
+// permutation of k on both sides.  Same MFMA count per MAC as bf16 (the non-scaled fp8 MFMA runs at the bf16 rate),
+// half the staged bytes.
+template <>
+__device__ __forceinline__ void mma_step<vv_fp8>(const uint4 &a, const uint4 &b, f32x16 &acc) {
+    const long alo = (long)(((unsigned long long)a.y << 32) | a.x), ahi = (long)(((unsigned long long)a.w << 32) | a.z);
+    const long blo = (long)(((unsigned long long)b.y << 32) | b.x), bhi = (long)(((unsigned long long)b.w << 32) | b.z);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(alo, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(ahi, bhi, acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma_step<float>(const uint4 &a, const uint4 &b, f32x16 &acc) {
@@ -464,8 +476,8 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
     // quad.  Each quad gets the folded BN + activation as a float4, is packed (8 B of bf16 / 16 B of f32) into a
     // [BM][BN] row-major LDS tile, and the tile leaves as 16-byte stores: whole channel rows, coalesced.  The
     // activation / output kind are hoisted into template parameters so the hot code has no per-element branches.
-    const int okind = a.partial ? 2 : (a.out_bf16 ? 0 : 1);
-    const int es = okind == 0 ? 2 : 4;
+    const int okind = a.partial ? 2 : a.out_kind;
+    const int es = okind == 0 ? 2 : (okind == 3 ? 1 : 4);
     const int pitch = BN * es + 16;
     // Folded BN quads of this lane's channels, fetched as one batch (two uniform branches, one wait) instead of a
     // dependent load + wait per quad.
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
                         float t = acc[i][j][4 * g + e];
                         if (KIND != 2) {
                             t = t * sc[e] + sh[e];
-                            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = KIND == 0 ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
+                            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = (KIND == 0 || KIND == 3) ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
                             else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                             else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
                         }
@@ -520,6 +532,8 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
                         *reinterpret_cast<bf16x4 *>(smem + rl * pitch + cl * 2) = o;
+                    } else if (KIND == 3) {
+                        *reinterpret_cast<unsigned *>(smem + rl * pitch + cl) = vv_pack_fp8x4(v);
                     } else {
                         *reinterpret_cast<f32x4 *>(smem + rl * pitch + cl * 4) = v;
                     }
@@ -530,6 +544,7 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
     auto with_kind = [&](auto act_c) {
         if (okind == 0) fill(act_c, std::integral_constant<int, 0>{});
         else if (okind == 1) fill(act_c, std::integral_constant<int, 1>{});
+        else if (okind == 3) fill(act_c, std::integral_constant<int, 3>{});
         else fill(act_c, std::integral_constant<int, 2>{});
     };
     switch (a.partial ? VV_ACT_NONE : a.act) {
@@ -572,16 +587,18 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmArgs a, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float t = s[q] * sc[q] + sh[q];
-            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = a.out_bf16 ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
+            if (ACT == VV_ACT_ELU) { const float tn = fminf(t, 0.f), em = a.out_kind != 1 ? __expf(tn) - 1.f : expm1f(tn); t = t > 0.f ? t : em; }
             else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
             else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
             v[q] = t;
         }
-        if (a.out_bf16) {
+        if (a.out_kind == 0) {
             bf16x4 ob;
 #pragma unroll
             for (int q = 0; q < 4; ++q) ob[q] = static_cast<__bf16>(v[q]);
             *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(a.Out) + o) = ob;
+        } else if (a.out_kind == 3) {
+            *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(a.Out) + o) = vv_pack_fp8x4(v);
         } else {
             *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(a.Out) + o) = v;
         }
@@ -599,7 +616,7 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     p.nparity = mode == MODE_CONVT ? 8 : 1;
     p.bm = 128;
     p.bn = (N % 128 == 0) ? 128 : 64;  // N tail (N % 64 != 0): weight rows past N read as zero, stores masked
-    const int bk = dtype == VV_BF16 ? 64 : 32;
+    const int bk = dtype == VV_BF16 ? 64 : (dtype == VV_FP8 ? 128 : 32);
     const int nchunks = (K + bk - 1) / bk;
     const long tiles = (long)((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn) * p.nparity;
     static const long target = getenv("VV_SPLIT_TARGET") ? atol(getenv("VV_SPLIT_TARGET")) : 512;
@@ -681,10 +698,12 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
               int K, int din, int cin, int act, int dtype, int out_dtype, void *ws, size_t ws_bytes, void *stream,
               int batch = 1) {
     if (!x || !w || !y) return VV_ERR_NULL;
-    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (out_dtype != VV_F32 && out_dtype != VV_BF16) return VV_ERR_DTYPE;
-    const int bk = dtype == VV_BF16 ? 64 : 32;
-    if (M <= 0 || N <= 0 || K <= 0 || N % (out_dtype == VV_BF16 ? 8 : 4)) return VV_ERR_SHAPE;
+    if (dtype != VV_F32 && dtype != VV_BF16 && dtype != VV_FP8) return VV_ERR_DTYPE;
+    if (out_dtype != VV_F32 && out_dtype != VV_BF16 && out_dtype != VV_FP8) return VV_ERR_DTYPE;
+    if (mode == MODE_FIRST && dtype == VV_FP8) return VV_ERR_DTYPE;
+    if (dtype == VV_F32 && out_dtype == VV_FP8) return VV_ERR_DTYPE;          // fp8 activations come from the bf16 / fp8 MFMA paths
+    const int bk = dtype == VV_BF16 ? 64 : (dtype == VV_FP8 ? 128 : 32);
+    if (M <= 0 || N <= 0 || K <= 0 || N % (out_dtype == VV_BF16 ? 8 : (out_dtype == VV_FP8 ? 16 : 4))) return VV_ERR_SHAPE;
     if (mode == MODE_DENSE ? (K % (bk / 8)) != 0 : (K % bk) != 0) return VV_ERR_SHAPE;
     if (mode == MODE_FIRST && (!vv_is_pow2(din) || cin != 1)) return VV_ERR_SHAPE;
     if ((mode == MODE_CONV || mode == MODE_CONVT) && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
@@ -705,7 +724,7 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     a.nchunks = (K + bk - 1) / bk;
     a.chunks_per_split = p.cps;
     a.act = act;
-    a.out_bf16 = out_dtype == VV_BF16;
+    a.out_kind = out_dtype == VV_BF16 ? 0 : (out_dtype == VV_FP8 ? 3 : 1);
     a.batch = batch;
     a.a_bytes = (unsigned)a_bytes;
     a.w_bytes = (unsigned)((size_t)p.nparity * N * K * vv_dtype_size(dtype));
@@ -718,6 +737,11 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
         if (mode == MODE_DENSE) return launch_t<__bf16, MODE_DENSE>(a, p, st);
         if (mode == MODE_CONV) return launch_t<__bf16, MODE_CONV>(a, p, st);
         return launch_t<__bf16, MODE_CONVT>(a, p, st);
+    }
+    if (dtype == VV_FP8) {
+        if (mode == MODE_DENSE) return launch_t<vv_fp8, MODE_DENSE>(a, p, st);
+        if (mode == MODE_CONV) return launch_t<vv_fp8, MODE_CONV>(a, p, st);
+        return launch_t<vv_fp8, MODE_CONVT>(a, p, st);
     }
     if (mode == MODE_DENSE) return launch_t<float, MODE_DENSE>(a, p, st);
     if (mode == MODE_CONV) return launch_t<float, MODE_CONV>(a, p, st);
@@ -741,6 +765,16 @@ VV_EXPORT int vv_conv3d_k4s2_fwd(const void *x, const void *w_packed, const floa
                      dtype, workspace, workspace_bytes, stream, batch);
 }
 
+VV_EXPORT int vv_conv3d_k4s2_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                    int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    if (batch <= 0 || side < 2 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
+    const int o = side / 2;
+    if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
+    return run_igemm(MODE_CONV, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64 * cin, side, cin, act, dtype,
+                     out_dtype, workspace, workspace_bytes, stream, batch);
+}
+
 VV_EXPORT size_t vv_convT3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, int dtype) {
     return make_plan(MODE_CONVT, batch * side * side * side, cout, 8 * cin, dtype).ws_bytes;
 }
@@ -752,6 +786,15 @@ VV_EXPORT int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const flo
     if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
     return run_igemm(MODE_CONVT, x, w_packed, scale, shift, y, batch * side * side * side, cout, 8 * cin, side, cin, act,
                      dtype, dtype, workspace, workspace_bytes, stream, batch);
+}
+
+VV_EXPORT int vv_convT3d_k4s2_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                     int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (batch <= 0 || side < 1 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
+    if ((long)batch * side * side * side * cin >= (1L << 31)) return VV_ERR_SHAPE;
+    return run_igemm(MODE_CONVT, x, w_packed, scale, shift, y, batch * side * side * side, cout, 8 * cin, side, cin, act,
+                     dtype, out_dtype, workspace, workspace_bytes, stream, batch);
 }
 
 VV_EXPORT size_t vv_dense_workspace_bytes(int m, int n, int k, int dtype) { return make_plan(MODE_DENSE, m, n, k, dtype).ws_bytes; }

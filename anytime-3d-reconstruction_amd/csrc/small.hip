@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void pack_conv_k4_tiled_kernel(const float *__
         const f32x4 v = {tile[kq + e][col], tile[kq + e + 1][col], tile[kq + e + 2][col], tile[kq + e + 3][col]};
         if constexpr (sizeof(T) == 4) {
             *reinterpret_cast<f32x4 *>(dst + e) = v;
+        } else if constexpr (sizeof(T) == 1) {
+            *reinterpret_cast<unsigned *>(dst + e) = vv_pack_fp8x4(v);
         } else {
             bf16x4 o;
 #pragma unroll
@@ -66,6 +68,8 @@ __global__ void pack_convT_k4s2_vec_kernel(const float *__restrict__ w, T *__res
         const f32x4 v = *reinterpret_cast<const f32x4 *>(w + ((size_t)t * cout + co) * cin + ci);
         if constexpr (sizeof(T) == 4) {
             reinterpret_cast<f32x4 *>(out)[i4] = v;
+        } else if constexpr (sizeof(T) == 1) {
+            reinterpret_cast<unsigned *>(out)[i4] = vv_pack_fp8x4(v);
         } else {
             bf16x4 o;
 #pragma unroll
@@ -239,7 +243,18 @@ __global__ void pack_bits_kernel(const float *__restrict__ x, unsigned char *__r
 
 template <typename TS, typename TD>
 __global__ void convert_kernel(const TS *__restrict__ src, TD *__restrict__ dst, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = static_cast<TD>((float)src[i]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) vv_store(dst, (size_t)i, vv_load_f32(src, (size_t)i));
+}
+
+// bf16 -> fp8, 8 elements per thread (n % 8 == 0): the hand-over from the bf16-only layers to the fp8 MFMA layers
+__global__ void convert_bf16_fp8_kernel(const bf16x8 *__restrict__ src, u32x2 *__restrict__ dst, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 v = src[i];
+        u32x2 o;
+        o[0] = vv_pack_fp8x4(f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]});
+        o[1] = vv_pack_fp8x4(f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]});
+        dst[i] = o;
+    }
 }
 
 }  // namespace
@@ -247,11 +262,14 @@ __global__ void convert_kernel(const TS *__restrict__ src, TD *__restrict__ dst,
 #define VV_PACK_DISPATCH(KERNEL, TOTAL, ...)                                                                   \
     do {                                                                                                       \
         if (!w_keras || !packed) return VV_ERR_NULL;                                                           \
-        if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;                                          \
+        if (dtype != VV_F32 && dtype != VV_BF16 && dtype != VV_FP8) return VV_ERR_DTYPE;                       \
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);                                                \
         if (dtype == VV_BF16)                                                                                  \
             VV_LAUNCH((KERNEL<__bf16>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,             \
                                reinterpret_cast<__bf16 *>(packed), __VA_ARGS__);                               \
+        else if (dtype == VV_FP8)                                                                              \
+            VV_LAUNCH((KERNEL<vv_fp8>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,             \
+                               reinterpret_cast<vv_fp8 *>(packed), __VA_ARGS__);                               \
         else                                                                                                   \
             VV_LAUNCH((KERNEL<float>), dim3(grid_for(TOTAL)), dim3(256), 0, st, w_keras,              \
                                reinterpret_cast<float *>(packed), __VA_ARGS__);                                \
@@ -279,10 +297,11 @@ VV_EXPORT const char *vv_status_string(int s) {
 
 VV_EXPORT int vv_pack_conv_k4(const float *w_keras, void *packed, int cin, int cout, int dtype, void *stream) {
     if (cin <= 0 || cout <= 0) return VV_ERR_SHAPE;
-    if (w_keras && packed && cout % 64 == 0 && (dtype == VV_F32 || dtype == VV_BF16) && vv_aligned16(w_keras) && vv_aligned16(packed)) {
+    if (w_keras && packed && cout % 64 == 0 && (dtype == VV_F32 || dtype == VV_BF16 || dtype == VV_FP8) && vv_aligned16(w_keras) && vv_aligned16(packed)) {
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const dim3 grid(cin, cout / 64);                 // K / 64 = cin
-        if (dtype == VV_BF16) VV_LAUNCH(pack_conv_k4_tiled_kernel<__bf16>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<__bf16 *>(packed), cin, cout);
+        if (dtype == VV_FP8) VV_LAUNCH(pack_conv_k4_tiled_kernel<vv_fp8>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<vv_fp8 *>(packed), cin, cout);
+        else if (dtype == VV_BF16) VV_LAUNCH(pack_conv_k4_tiled_kernel<__bf16>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<__bf16 *>(packed), cin, cout);
         else VV_LAUNCH(pack_conv_k4_tiled_kernel<float>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<float *>(packed), cin, cout);
         return vv_launch_status();
     }
@@ -369,11 +388,24 @@ VV_EXPORT int vv_pack_bits(const float *x, void *packed, float threshold, long n
 
 VV_EXPORT int vv_convert(const void *src, void *dst, long n, int src_dtype, int dst_dtype, void *stream) {
     if (!src || !dst) return VV_ERR_NULL;
-    if ((src_dtype != VV_F32 && src_dtype != VV_BF16) || (dst_dtype != VV_F32 && dst_dtype != VV_BF16)) return VV_ERR_DTYPE;
+    if (src_dtype != VV_F32 && src_dtype != VV_BF16 && src_dtype != VV_FP8) return VV_ERR_DTYPE;
+    if (dst_dtype != VV_F32 && dst_dtype != VV_BF16 && dst_dtype != VV_FP8) return VV_ERR_DTYPE;
     if (n <= 0) return VV_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 g(grid_for((size_t)n)), b(256);
-    if (src_dtype == VV_F32 && dst_dtype == VV_BF16)
+    if (src_dtype == VV_BF16 && dst_dtype == VV_FP8 && n % 8 == 0 && vv_aligned16(src) && vv_aligned16(dst))
+        VV_LAUNCH(convert_bf16_fp8_kernel, dim3(grid_for((size_t)(n / 8))), b, 0, st, reinterpret_cast<const bf16x8 *>(src), reinterpret_cast<u32x2 *>(dst), n / 8);
+    else if (dst_dtype == VV_FP8 && src_dtype == VV_F32)
+        VV_LAUNCH((convert_kernel<float, vv_fp8>), g, b, 0, st, reinterpret_cast<const float *>(src), reinterpret_cast<vv_fp8 *>(dst), n);
+    else if (dst_dtype == VV_FP8 && src_dtype == VV_BF16)
+        VV_LAUNCH((convert_kernel<__bf16, vv_fp8>), g, b, 0, st, reinterpret_cast<const __bf16 *>(src), reinterpret_cast<vv_fp8 *>(dst), n);
+    else if (src_dtype == VV_FP8 && dst_dtype == VV_F32)
+        VV_LAUNCH((convert_kernel<vv_fp8, float>), g, b, 0, st, reinterpret_cast<const vv_fp8 *>(src), reinterpret_cast<float *>(dst), n);
+    else if (src_dtype == VV_FP8 && dst_dtype == VV_BF16)
+        VV_LAUNCH((convert_kernel<vv_fp8, __bf16>), g, b, 0, st, reinterpret_cast<const vv_fp8 *>(src), reinterpret_cast<__bf16 *>(dst), n);
+    else if (src_dtype == VV_FP8)
+        return VV_ERR_DTYPE;
+    else if (src_dtype == VV_F32 && dst_dtype == VV_BF16)
         VV_LAUNCH((convert_kernel<float, __bf16>), g, b, 0, st, reinterpret_cast<const float *>(src), reinterpret_cast<__bf16 *>(dst), n);
     else if (src_dtype == VV_BF16 && dst_dtype == VV_F32)
         VV_LAUNCH((convert_kernel<__bf16, float>), g, b, 0, st, reinterpret_cast<const __bf16 *>(src), reinterpret_cast<float *>(dst), n);

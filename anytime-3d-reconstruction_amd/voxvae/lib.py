@@ -12,9 +12,9 @@ import torch  # noqa: F401  -- FIRST: libvoxvae must bind to the HIP runtime tor
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae.so')
 
-VV_F32, VV_BF16 = 0, 1
+VV_F32, VV_BF16, VV_FP8 = 0, 1, 2
 ACT = {None: 0, 'None': 0, 'linear': 0, 'elu': 1, 'relu': 2, 'lrelu': 3}
-DTYPES = {'f32': VV_F32, 'fp32': VV_F32, 'float32': VV_F32, 'bf16': VV_BF16, 'bfloat16': VV_BF16}
+DTYPES = {'f32': VV_F32, 'fp32': VV_F32, 'float32': VV_F32, 'bf16': VV_BF16, 'bfloat16': VV_BF16, 'fp8': VV_FP8}
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
@@ -34,6 +34,8 @@ SIGNATURES = {
     'vv_conv3d_k4s2_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_convT3d_k4s2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'vv_convT3d_k4s2_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_conv3d_k4s2_fwd_io': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_convT3d_k4s2_fwd_io': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_conv3d_k4s2_direct_supported': (_i, [_i, _i, _i, _i]),
     'vv_conv3d_k4s2_direct_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_convT3d_k4s2_direct_supported': (_i, [_i, _i, _i, _i]),

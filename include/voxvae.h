@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-typedef enum { VV_F32 = 0, VV_BF16 = 1 } vv_dtype;
+typedef enum { VV_F32 = 0, VV_BF16 = 1, VV_FP8 = 2 /* OCP e4m3fn, 1 byte; MFMA layers with cin % 128 == 0 only */ } vv_dtype;
 typedef enum { VV_ACT_NONE = 0, VV_ACT_ELU = 1, VV_ACT_RELU = 2, VV_ACT_LRELU = 3 } vv_act;
 typedef enum {
     VV_OK = 0,
@@ -86,6 +86,18 @@ size_t vv_convT3d_k4s2_workspace_bytes(int batch, int side, int cin, int cout, i
 int vv_convT3d_k4s2_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
                         int batch, int side, int cin, int cout, int act, int dtype, void *workspace,
                         size_t workspace_bytes, void *stream);
+
+/* The two stride-2 layers with separate operand / output element types: dtype VV_FP8 runs the implicit GEMM on
+ * v_mfma_f32_32x32x16_fp8_fp8 (x and w_packed in OCP e4m3fn, one byte per element; cin % 128 == 0; per-output-channel
+ * weight scales belong in `scale`), out_dtype chooses what the epilogue stores (VV_FP8 for the next fp8 layer, VV_BF16
+ * for a bf16 consumer, VV_F32).  dtype VV_BF16 with out_dtype VV_FP8 is the hand-over into an fp8 stretch.  New in this
+ * build (BASELINE config 5): the reference is float32 only.  Workspace: the *_workspace_bytes query with `dtype`. */
+int vv_conv3d_k4s2_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                          int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int vv_convT3d_k4s2_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                           int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* Direct variant of vv_conv3d_k4s2_fwd for the widest encoder layer (bf16, Cin 64 -> Cout 128, side >= 16): per input
  * phase q (x index parity per axis) the layer is a k2 s1 convolution over the phase sub-grid, so a 4x8x8 box of

@@ -461,3 +461,117 @@ def test_wgrad_conv_phase_form(L, B, side, cin, cout, monkeypatch):
         err = np.abs(outs[-1] - ref).max()
         assert err <= 2e-5 * np.abs(ref).max() + 1e-5, ('phase off' if off else 'phase on', err)
     assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * np.abs(ref).max() + 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- fp8 (OCP e4m3fn) MFMA path
+F8 = getattr(torch, 'float8_e4m3fn', None)
+
+
+def _fp8_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(F8).float().numpy()
+
+
+def _check_fp8_out(got_f8, ref, what):
+    got = got_f8.float().cpu().numpy().astype(np.float64)
+    # e4m3: 3 mantissa bits (half an ulp = 2^-4 relative), subnormal spacing 2^-9
+    bad = np.abs(got - ref) > 0.0635 * np.abs(ref) + 2.5e-3
+    assert not bad.any(), '%s: %d of %d beyond fp8 rounding, worst %.3e' % (what, bad.sum(), bad.size, np.abs(got - ref).max())
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,side,cin,cout,odt', [(2, 8, 128, 256, 'bf16'), (2, 8, 128, 256, 'fp8'), (37, 4, 256, 512, 'fp8'), (1, 16, 128, 64, 'f32')])
+def test_conv3d_k4s2_fp8(L, B, side, cin, cout, odt):
+    """Stride-2 Conv3D on the fp8 MFMA (operands e4m3fn, float32 accumulation, per-channel scales in `scale`) against the
+    float64 definition on the same fp8-representable operands; outputs bf16 / fp8 / f32."""
+    rng = np.random.default_rng(B + side)
+    x = _fp8_round(rng.standard_normal((B, side, side, side, cin)))
+    w = _fp8_round(rng.standard_normal((4, 4, 4, cin, cout)))
+    scale = (rng.uniform(0.5, 1.5, cout) / np.sqrt(64 * cin)).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
+    xd = _dev(x).to(F8)
+    wp = torch.empty(cout, 64 * cin, dtype=F8, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(_dev(w)), L.ptr(wp), cin, cout, L.VV_FP8, _st())
+    torch.cuda.synchronize()
+    assert np.array_equal(wp.float().cpu().numpy(), w.reshape(64 * cin, cout).T)          # packing fp8-representable values is exact
+    so = side // 2
+    tout = {'bf16': torch.bfloat16, 'fp8': F8, 'f32': torch.float32}[odt]
+    y = torch.zeros(B, so, so, so, cout, dtype=tout, device=DEV)
+    ws = torch.empty(max(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, cin, cout, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
+    sd, hd = _dev(scale), _dev(shift)
+    L.call('vv_conv3d_k4s2_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, 1, L.VV_FP8, L.DTYPES[odt],
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    if odt == 'fp8':
+        _check_fp8_out(y, ref, 'conv3d fp8->fp8')
+    else:
+        _check(y, ref, odt, 'conv3d fp8->' + odt)
+    # cin not a multiple of 128 has no fp8 form
+    assert L.load().vv_conv3d_k4s2_fwd_io(L.ptr(xd), L.ptr(wp), None, None, L.ptr(y), B, side, 64, cout, 0, L.VV_FP8, L.DTYPES[odt],
+                                          L.ptr(ws), ws.numel(), _st()) == -2
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,side,cin,cout,odt', [(2, 4, 256, 128, 'fp8'), (3, 8, 128, 64, 'bf16'), (33, 2, 512, 256, 'fp8')])
+def test_convT3d_k4s2_fp8(L, B, side, cin, cout, odt):
+    rng = np.random.default_rng(B * 7 + side)
+    x = _fp8_round(rng.standard_normal((B, side, side, side, cin)))
+    w = _fp8_round(rng.standard_normal((4, 4, 4, cout, cin)))
+    scale = (rng.uniform(0.5, 1.5, cout) / np.sqrt(8 * cin)).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
+    xd = _dev(x).to(F8)
+    wp = torch.empty(8, cout, 8 * cin, dtype=F8, device=DEV)
+    L.call('vv_pack_convT_k4s2', L.ptr(_dev(w)), L.ptr(wp), cin, cout, L.VV_FP8, _st())
+    tout = {'bf16': torch.bfloat16, 'fp8': F8}[odt]
+    y = torch.zeros(B, 2 * side, 2 * side, 2 * side, cout, dtype=tout, device=DEV)
+    ws = torch.empty(max(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, cin, cout, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
+    sd, hd = _dev(scale), _dev(shift)
+    L.call('vv_convT3d_k4s2_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, 1, L.VV_FP8, L.DTYPES[odt],
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    if odt == 'fp8':
+        _check_fp8_out(y, ref, 'convT3d fp8->fp8')
+    else:
+        _check(y, ref, odt, 'convT3d fp8->bf16')
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+def test_dense_and_convert_fp8(L):
+    rng = np.random.default_rng(5)
+    m, n, k = 37, 128, 4096
+    x = _fp8_round(rng.standard_normal((m, k)))
+    w = _fp8_round(rng.standard_normal((k, n)))
+    scale = (rng.uniform(0.5, 1.5, n) / np.sqrt(k)).astype(np.float32)
+    ref = (x.astype(np.float64) @ w.astype(np.float64)) * scale
+    wp = torch.empty(n, k, dtype=F8, device=DEV)
+    L.call('vv_pack_dense', L.ptr(_dev(w)), L.ptr(wp), k, n, L.VV_FP8, _st())
+    y = torch.zeros(m, n, dtype=torch.float32, device=DEV)
+    ws = torch.empty(max(L.load().vv_dense_workspace_bytes(m, n, k, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
+    L.call('vv_dense_fwd', L.ptr(_dev(x).to(F8)), L.ptr(wp), L.ptr(_dev(scale)), None, L.ptr(y), m, n, k, 0, L.VV_FP8, L.VV_F32, L.ptr(ws),
+           ws.numel(), _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'f32', 'dense fp8->f32')
+    # bf16 operands, fp8 output (the hand-over into an fp8 stretch)
+    xb, wb = _bf16_round(rng.standard_normal((m, 256)).astype(np.float32)), _bf16_round(rng.standard_normal((256, n)).astype(np.float32) / 16)
+    ref2 = xb.astype(np.float64) @ wb.astype(np.float64)
+    wpb = torch.empty(n, 256, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_dense', L.ptr(_dev(wb)), L.ptr(wpb), 256, n, L.VV_BF16, _st())
+    y8 = torch.zeros(m, n, dtype=F8, device=DEV)
+    ws = torch.empty(max(L.load().vv_dense_workspace_bytes(m, n, 256, L.VV_BF16), 16), dtype=torch.uint8, device=DEV)
+    L.call('vv_dense_fwd', L.ptr(_dev(xb, torch.bfloat16)), L.ptr(wpb), None, None, L.ptr(y8), m, n, 256, 0, L.VV_BF16, L.VV_FP8, L.ptr(ws),
+           ws.numel(), _st())
+    torch.cuda.synchronize()
+    _check_fp8_out(y8, ref2, 'dense bf16->fp8')
+    # conversions: bf16 -> fp8 rounds to nearest (checked against torch's cast), saturates at 448; fp8 -> f32 is exact
+    v = _bf16_round((rng.standard_normal(4096) * np.exp(rng.uniform(-6, 6, 4096))).astype(np.float32))
+    v[:4] = [1000.0, -1000.0, 448.0, 0.0]
+    vd = _dev(v, torch.bfloat16)
+    o8 = torch.zeros(4096, dtype=F8, device=DEV)
+    L.call('vv_convert', L.ptr(vd), L.ptr(o8), 4096, L.VV_BF16, L.VV_FP8, _st())
+    back = torch.zeros(4096, dtype=torch.float32, device=DEV)
+    L.call('vv_convert', L.ptr(o8), L.ptr(back), 4096, L.VV_FP8, L.VV_F32, _st())
+    torch.cuda.synchronize()
+    want = torch.from_numpy(np.clip(v, -448, 448)).to(F8).float().numpy()
+    assert np.array_equal(back.cpu().numpy(), want)
+    assert np.array_equal(o8.float().cpu().numpy(), want)
