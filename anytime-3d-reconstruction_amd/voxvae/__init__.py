@@ -11,8 +11,9 @@ _DEFAULTS = {'dtype': os.environ.get('VOXVAE_DTYPE', 'f32'), 'device': os.enviro
 
 
 def set_default_dtype(dtype):
-    """'f32' (exact-f32 MFMA, the reference's arithmetic type; default) or 'bf16' (bf16 MFMA, f32 accumulate)."""
-    if dtype not in ('f32', 'bf16'):
+    """'f32' (exact-f32 MFMA, the reference's arithmetic type; default), 'bf16' (bf16 MFMA, f32 accumulate) or 'fp8'
+    (inference only: the MFMA layers with Cin % 128 == 0 on e4m3fn operands with per-channel weight scales, the rest bf16)."""
+    if dtype not in ('f32', 'bf16', 'fp8'):
         raise ValueError(dtype)
     _DEFAULTS['dtype'] = dtype
 

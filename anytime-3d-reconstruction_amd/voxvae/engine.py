@@ -74,6 +74,12 @@ class _EngineBase:
         L.load()
         self.structure = structure
         self.dt = L.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        # 'fp8': inference mode in which the MFMA layers whose Cin is a multiple of 128 run on e4m3fn operands (weights
+        # quantised per output channel, the scale folded into the BatchNorm scale; activations stored as fp8 between
+        # consecutive fp8 layers); every other layer, the latent algebra and the losses are the bf16 path.
+        self.fp8 = self.dt == L.VV_FP8
+        if self.fp8:
+            self.dt = L.VV_BF16
         self.tdt = _tdtype(self.dt)
         self.device = torch.device(device)
         self.params = {}          # name -> float32 CUDA tensor, Keras layout (the trainable/master copy)
@@ -117,6 +123,21 @@ class _EngineBase:
 
     def _empty(self, *shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+
+    def _quant_fp8(self, w, cout_axis):
+        """Per-output-channel scaling ahead of the fp8 pack: (w / s, s) with s = max|w| / 256 per channel (e4m3fn holds
+        +-448; relative precision does not depend on the scale, the range does)."""
+        red = [d for d in range(w.dim()) if d != cout_axis]
+        s = w.abs().amax(dim=red).clamp_min(1e-20) / 256.0
+        shape = [1] * w.dim()
+        shape[cout_axis] = -1
+        return (w / s.view(shape)).contiguous(), s.contiguous()
+
+    def _as_fp8(self, h, label):
+        """bf16 activation -> fp8 copy (the hand-over from a bf16-only layer into an fp8 stretch)."""
+        o = torch.empty(h.shape, dtype=torch.uint8, device=self.device)
+        self._call(label, 'vv_convert', L.ptr(h), L.ptr(o), h.numel(), L.VV_BF16, L.VV_FP8, _stream())
+        return o
 
     def ensure_packed(self, fold=True):
         """Refresh the packed weight images after a weight change.  fold=False (the training step, which uses batch
@@ -175,13 +196,26 @@ class EncoderEngine(_EngineBase):
         self.packed['w0'] = self._empty(f[0], 64)
         L.call('vv_pack_conv_k4', L.ptr(p['conv0/kernel']), L.ptr(self.packed['w0']), 1, f[0], self.dt, st)
         for i in range(1, len(f) - 1):
-            w = self._empty(f[i], 64 * f[i - 1])
-            L.call('vv_pack_conv_k4', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), f[i - 1], f[i], self.dt, st)
+            q = self.fp8 and f[i - 1] % 128 == 0
+            wk = p['conv%d/kernel' % i]
+            if q:
+                wk, qs = self._quant_fp8(wk, 4)
+            w = self._empty(f[i], 64 * f[i - 1], dtype=torch.uint8 if q else None)
+            L.call('vv_pack_conv_k4', L.ptr(wk), L.ptr(w), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
             self.packed['w%d' % i] = w
             self.packed['scale%d' % i], self.packed['shift%d' % i] = self._fold('bn%d' % i, f[i])
+            if q:
+                self.packed['q%d' % i] = True
+                if self.packed['scale%d' % i] is not None:
+                    self.packed['scale%d' % i].mul_(qs)
         i = len(f) - 1
-        w = self._empty(f[i], self.S ** 3 * f[i - 1])
-        L.call('vv_pack_conv_k4s1_meanpool', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), self.S, f[i - 1], f[i], self.dt, st)
+        q = self.fp8 and (self.S ** 3 * f[i - 1]) % 128 == 0
+        wk = p['conv%d/kernel' % i]
+        if q:
+            wk, qs = self._quant_fp8(wk, 4)
+            self.packed['q%d' % i], self.packed['scale%d' % i] = True, qs
+        w = self._empty(f[i], self.S ** 3 * f[i - 1], dtype=torch.uint8 if q else None)
+        L.call('vv_pack_conv_k4s1_meanpool', L.ptr(wk), L.ptr(w), self.S, f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
         self.packed['w%d' % i] = w
 
     def forward(self, x):
@@ -194,24 +228,41 @@ class EncoderEngine(_EngineBase):
         h = self._empty(B, side, side, side, f[0])
         self._call('E1', 'vv_conv3d_first_fwd', L.ptr(x), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
                L.ptr(h), B, D, f[0], self.act, self.dt, st)
+        hdt = self.dt                                        # element type of h: the engine's dtype, or fp8 inside an fp8 stretch
         for i in range(1, len(f) - 1):
-            o = self._empty(B, side // 2, side // 2, side // 2, f[i])
-            if not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
-                self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
+            q, nq = pk.get('q%d' % i, False), pk.get('q%d' % (i + 1), False)
+            odt = L.VV_FP8 if nq else self.dt
+            name = 'E%d' % (i + 1)
+            if q:
+                if hdt != L.VV_FP8:
+                    h = self._as_fp8(h, name + 'c')
+                o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
+                ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], L.VV_FP8))
+                self._call(name, 'vv_conv3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                           L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
+                hdt = odt
+            elif not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
+                o = self._empty(B, side // 2, side // 2, side // 2, f[i])
+                self._call(name, 'vv_conv3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
                            L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                hdt = self.dt
             else:
-                nb = L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt)
-                ws = self.ws.get(nb)
-                self._call('E%d' % (i + 1), 'vv_conv3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
-                           L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+                o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
+                ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))
+                self._call(name, 'vv_conv3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                           L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, odt, L.ptr(ws), ws.numel(), st)
+                hdt = odt
             h, side = o, side // 2
         i = len(f) - 1
         K = side ** 3 * f[i - 1]
-        nb = L.load().vv_dense_workspace_bytes(B, f[i], K, self.dt)
-        ws = self.ws.get(nb)
+        q = pk.get('q%d' % i, False)
+        if q and hdt != L.VV_FP8:
+            h = self._as_fp8(h, 'E%dc' % (i + 1))
+        ddt = L.VV_FP8 if q else self.dt
+        ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, f[i], K, ddt))
         out = self._empty(B, f[i], dtype=torch.float32)
-        self._call('E%d' % (i + 1), 'vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), None, None, L.ptr(out), B, f[i], K, 0, self.dt, L.VV_F32,
-               L.ptr(ws), ws.numel(), st)
+        self._call('E%d' % (i + 1), 'vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk.get('scale%d' % i)), None, L.ptr(out), B, f[i], K, 0,
+                   ddt, L.VV_F32, L.ptr(ws), ws.numel(), st)
         return out
 
 
@@ -261,12 +312,24 @@ class DecoderEngine(_EngineBase):
         pk['w0'] = self._empty(S3 * f[0], lin)
         L.call('vv_pack_convT_k4s1_dense', L.ptr(p['convT0/kernel']), L.ptr(pk['w0']), self.S, self.ch, f[0], self.dt, st)
         pk['scale0'], pk['shift0'] = self._fold('bnT0', f[0], S3)
+        # fp8 mode: the stride-2 layers with Cin % 128 == 0 run on fp8 operands; the last of them (128 -> 64) only when
+        # VV_FP8_LAST is set -- its bf16 direct kernel is faster than the fp8 implicit GEMM (measured)
+        last = len(f) - 2
         for i in range(1, len(f) - 1):
-            pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1])
-            L.call('vv_pack_convT_k4s2', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['w%d' % i]), f[i - 1], f[i], self.dt, st)
-            pk['scale%d' % i], pk['shift%d' % i] = self._fold('bnT%d' % i, f[i])
             side_i = self.S << (i - 1)
-            if not os.environ.get('VV_NO_DIRECT') and L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt):
+            direct = not os.environ.get('VV_NO_DIRECT') and bool(L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt))
+            q = self.fp8 and f[i - 1] % 128 == 0 and not (direct and i == last and not os.environ.get('VV_FP8_LAST'))
+            wk = p['convT%d/kernel' % i]
+            if q:
+                wk, qs = self._quant_fp8(wk, 3)
+            pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1], dtype=torch.uint8 if q else None)
+            L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(pk['w%d' % i]), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
+            pk['scale%d' % i], pk['shift%d' % i] = self._fold('bnT%d' % i, f[i])
+            if q:
+                pk['q%d' % i] = True
+                if pk['scale%d' % i] is not None:
+                    pk['scale%d' % i].mul_(qs)
+            elif direct:
                 pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
 
@@ -285,21 +348,29 @@ class DecoderEngine(_EngineBase):
                self.L, self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
         n0 = S ** 3 * f[0]
         ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, n0, lin, self.dt))
-        h = self._empty(B, S, S, S, f[0])
+        hdt = L.VV_FP8 if pk.get('q1', False) else self.dt          # D1 hands fp8 to an fp8 D2
+        h = self._empty(B, S, S, S, f[0], dtype=torch.uint8 if hdt == L.VV_FP8 else None)
         self._call('D1', 'vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
-               self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
+               self.act, self.dt, hdt, L.ptr(ws), ws.numel(), st)
         side = S
         for i in range(1, len(f) - 1):
-            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))
-            o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+            name = 'D%d' % (i + 1)
+            q, nq = pk.get('q%d' % i, False), pk.get('q%d' % (i + 1), False)
+            odt = L.VV_FP8 if nq else self.dt
             if ('wf%d' % i) in pk:
-                self._call('D%d' % (i + 1), 'vv_convT3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['wf%d' % i]), L.ptr(pk['scale%d' % i]),
+                o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+                self._call(name, 'vv_convT3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['wf%d' % i]), L.ptr(pk['scale%d' % i]),
                            L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
-                h, side = o, 2 * side
+                h, side, hdt = o, 2 * side, self.dt
                 continue
-            self._call('D%d' % (i + 1), 'vv_convT3d_k4s2_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
-                   L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
-            h, side = o, 2 * side
+            if q and hdt != L.VV_FP8:
+                h = self._as_fp8(h, name + 'c')
+            idt = L.VV_FP8 if q else self.dt
+            ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], idt))
+            o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i], dtype=torch.uint8 if nq else None)
+            self._call(name, 'vv_convT3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                   L.ptr(o), B, side, f[i - 1], f[i], self.act, idt, odt, L.ptr(ws), ws.numel(), st)
+            h, side, hdt = o, 2 * side, odt
         if target is None:
             target = torch.zeros(B, D, D, D, 1, dtype=torch.float32, device=self.device)
         elif target.dtype != torch.float32 or target.numel() != B * D ** 3 or not target.is_contiguous():

@@ -114,6 +114,8 @@ class Trainer:
     def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None):
         if enc is not None and enc.dt != dec.dt:
             raise ValueError('encoder and decoder engines must share one activation dtype')
+        if dec.fp8 or (enc is not None and enc.fp8):
+            raise ValueError("fit() runs in 'f32' or 'bf16'; 'fp8' is an inference mode (quantised weight images)")
         # 'f32': everything on the exact-f32 MFMA path (parity mode).  'bf16': mixed precision -- activations, their
         # gradients and the MFMA operands in bf16, float32 master weights / Adam moments / BatchNorm statistics / losses,
         # weight gradients accumulated in float32 (f32 MFMA over widened operands).

@@ -5,7 +5,7 @@ One "step" = one pass of the hot path over one batch: encoder -> clip|reparam|KL
 i.e. getEval(missing_prob=0) (reference nolbo.py:1463-1501), inputs resident in HBM.  Workload = BASELINE.json
 configs[1] (ModelNet40 VAE, 32^3, batch 256, bf16); synthetic voxels + random-init weights (no dataset/weights exist).
 
-    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32|fp8]
 For N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Eval shards the batch dimension: rank r runs its own 256 reconstructions (weak scaling), no data-path collective.
 
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, 'anytime-3d-reconstruction_amd'))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK = {'bf16': 2.5e15, 'f32': 157.3e12, 'fp8': 5.0e15}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'])
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--voxel', type=int, default=32)
     ap.add_argument('--latent', type=int, default=64)
@@ -67,7 +67,7 @@ def cpu_baseline_torch(cfg, ep, dp, x, eps, ref, n=64, min_seconds=5.0, max_pass
     """Secondary CPU bracket: the same graph on torch-CPU float32 ops (oneDNN convolutions, the library family
     TF-CPU dispatches to), bounded like the C leg; also cross-checks the two CPU statements against each other."""
     from oracle import torch_oracle as to
-    n = min(n, x.shape[0])
+    n = min(n, x.shape[0], ref['logits'].shape[0])
     lg, bce, tp, fp, fn = to.eval_forward_f32(cfg, ep, dp, x[:n], eps[:n])          # warm-up + agreement with the C oracle
     agree = float(np.abs(lg - ref['logits'][:n]).max())
     passes, dt = 0, 0.0
@@ -215,10 +215,16 @@ def main():
     if os.path.exists(tf) and a.dtype == 'bf16' and a.batch == 256 and a.voxel == 32:
         traffic = json.load(open(tf))['layers'].get(dominant, {}).get('hbm_bytes_per_launch')
 
+    def layer_dtype(name):
+        if a.dtype != 'fp8':
+            return a.dtype
+        eng = model._enc_eng if name.startswith('E') else model._dec_eng
+        return 'fp8' if eng.packed.get('q%d' % (int(name[1:]) - 1)) else 'bf16'
+
     if rank == 0:
         fl_rec, fl_dense = workload.flops_per_reconstruction(cfg)
         flops = 2.0 * lm[dominant] * a.batch                     # algorithmic (valid-tap) FLOPs of one launch
-        es = 2 if a.dtype == 'bf16' else 4
+        es = 4 if a.dtype == 'f32' else 2
         nlast = len(cfg['decoder']['filter_num_list'])
         half = (a.voxel // 2) ** 3
         if dominant == 'D%d' % nlast:        # decoder tail + losses: reads the widest activation + target, writes probabilities
@@ -231,15 +237,16 @@ def main():
                     'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (kms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
         else:
             achieved = flops / (kms * 1e-3)
-            roof = {'bound': 'mfma', 'kernel': 'conv kernel (%s, layer %s)' % (a.dtype, dominant), 'achieved': achieved / 1e12,
-                    'peak': PEAK[a.dtype] / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / PEAK[a.dtype], 'algorithmic_flops_per_launch': flops}
+            kdt = layer_dtype(dominant)           # in 'fp8' mode only the Cin % 128 == 0 layers run fp8 operands; the rest are bf16 kernels
+            roof = {'bound': 'mfma', 'kernel': 'conv kernel (%s, layer %s)' % (kdt, dominant), 'achieved': achieved / 1e12,
+                    'peak': PEAK[kdt] / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / PEAK[kdt], 'algorithmic_flops_per_launch': flops}
         roof.update({'traffic': traffic, 'launch_ms': kms, 'launches_timed': nl})
         # the heaviest MFMA layer as well, whatever is dominant
         mf = max((k for k in (breakdown or {}) if k not in ('E1', 'D%d' % nlast)), key=lambda k: (breakdown or {}).get(k, 0), default=None)
         mfma_layer = None
-        if mf is not None:
+        if mf is not None and mf in lm:
             mfma_layer = {'layer': mf, 'ms': breakdown[mf], 'TFLOPs': 2.0 * lm[mf] * a.batch / (breakdown[mf] * 1e-3) / 1e12,
-                          'frac_of_mfma_peak': 2.0 * lm[mf] * a.batch / (breakdown[mf] * 1e-3) / PEAK[a.dtype]}
+                          'frac_of_mfma_peak': 2.0 * lm[mf] * a.batch / (breakdown[mf] * 1e-3) / PEAK[layer_dtype(mf)]}
         out = {
             'metric': '32^3 voxel reconstructions/sec at batch=256; IoU delta vs reference',
             'value': world * a.batch * a.steps / el,

@@ -101,9 +101,10 @@ def test_f32_batch_invariance_and_c_oracle():
     np.testing.assert_allclose(big['stats'][12:, 0], c['bce'], rtol=1e-4)
 
 
-@pytest.mark.parametrize('dtname,B', [('f32', 8), ('bf16', 8)])
+@pytest.mark.parametrize('dtname,B', [('f32', 8), ('bf16', 8), ('fp8', 8)])
 def test_d64_vae_config_against_c_oracle(dtname, B):
-    """BASELINE configs 3/5 shape (the reference's native 64^3 grid, test_modelnet_VAE.py:174-189): D=64, L=64."""
+    """BASELINE configs 3/5 shape (the reference's native 64^3 grid, test_modelnet_VAE.py:174-189): D=64, L=64.  'fp8' is
+    config 5's arithmetic: E3-E5 / D2-D3 on e4m3fn operands, gated on the IoU delta like bf16."""
     from oracle import c_oracle as co
     from voxvae import synthetic as syn
     cfg = syn.make_config(64, 64, True)
