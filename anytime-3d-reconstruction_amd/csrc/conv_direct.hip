@@ -42,8 +42,8 @@ constexpr int CD_SP = CD_COUT * 2 + 16;           // epilogue row pitch
 
 __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
-                                                             __bf16 *__restrict__ y, int dout_log2, unsigned x_bytes, unsigned w_bytes,
-                                                             int act) {
+                                                             void *__restrict__ y, int dout_log2, unsigned x_bytes, unsigned w_bytes,
+                                                             int act, int out_fp8) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,8 +198,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
 #pragma unroll
             for (int g = 0; g < 4; ++g) shv[nt][g] = *reinterpret_cast<const f32x4 *>(shift + wn * 64 + nt * 32 + 8 * g + 4 * fh);
     }
-    auto fill = [&](auto act_c) {
+    auto fill = [&](auto act_c, auto fp8_c) {
         constexpr int ACT = decltype(act_c)::value;
+        constexpr bool FP8 = decltype(fp8_c)::value;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -208,32 +209,44 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
                 for (int g = 0; g < 4; ++g) {
                     const int c = wn * 64 + nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = scv[nt][g], sh = shv[nt][g];
-                    bf16x4 o;
+                    f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[nt][mt][4 * g + e] * sc[e] + sh[e];
                         if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
                         else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                         else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                        o[e] = static_cast<__bf16>(t);
+                        v[e] = t;
                     }
-                    *reinterpret_cast<bf16x4 *>(stage + (wm * 64 + mt * 32 + fr) * CD_SP + c * 2) = o;
+                    char *dst = stage + (wm * 64 + mt * 32 + fr) * CD_SP;
+                    if (FP8) {
+                        *reinterpret_cast<unsigned *>(dst + c) = vv_pack_fp8x4(v);
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
+                        *reinterpret_cast<bf16x4 *>(dst + c * 2) = o;
+                    }
                 }
     };
+    auto with_out = [&](auto act_c) {
+        if (out_fp8) fill(act_c, std::true_type{});
+        else fill(act_c, std::false_type{});
+    };
     switch (act) {
-        case VV_ACT_ELU: fill(std::integral_constant<int, VV_ACT_ELU>{}); break;
-        case VV_ACT_RELU: fill(std::integral_constant<int, VV_ACT_RELU>{}); break;
-        case VV_ACT_LRELU: fill(std::integral_constant<int, VV_ACT_LRELU>{}); break;
-        default: fill(std::integral_constant<int, VV_ACT_NONE>{}); break;
+        case VV_ACT_ELU: with_out(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: with_out(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: with_out(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: with_out(std::integral_constant<int, VV_ACT_NONE>{}); break;
     }
     __syncthreads();
-    constexpr int CPR = CD_COUT * 2 / 16;             // 16-byte chunks per output row
-#pragma unroll
-    for (int i = 0; i < 256 * CPR / 512; ++i) {
-        const int id = tid + 512 * i, r = id / CPR, cc = id % CPR;
+    const int es = out_fp8 ? 1 : 2;                   // the fp8 form hands the layer's output to an fp8 consumer (e4m3fn)
+    const int cpr = CD_COUT * es / 16;                // 16-byte chunks per output row
+    for (int id = tid; id < 256 * cpr; id += 512) {
+        const int r = id / cpr, cc = id % cpr;
         const int od = od0 + (r >> 6), oh = oh0 + ((r >> 3) & 7), ow = ow0 + (r & 7);
         const size_t vox = ((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow;
-        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (CD_COUT * 2) + cc * 16) =
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (CD_COUT * es) + cc * 16) =
             *reinterpret_cast<const uint4 *>(stage + r * CD_SP + cc * 16);
     }
 }
@@ -244,9 +257,10 @@ VV_EXPORT int vv_conv3d_k4s2_direct_supported(int side, int cin, int cout, int d
     return dtype == VV_BF16 && cin == CD_CIN && cout == CD_COUT && side >= 16 && vv_is_pow2(side);
 }
 
-VV_EXPORT int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
-                                        int batch, int side, int cin, int cout, int act, int dtype, void *stream) {
+VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                           int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *stream) {
     if (!x || !w_packed || !y) return VV_ERR_NULL;
+    if (out_dtype != VV_BF16 && out_dtype != VV_FP8) return VV_ERR_DTYPE;
     if (!vv_conv3d_k4s2_direct_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w_packed) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const size_t xb = (size_t)batch * side * side * side * cin * 2;
@@ -259,7 +273,12 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, con
     }();
     (void)attr;
     VV_LAUNCH(conv_direct_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
-              reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, reinterpret_cast<__bf16 *>(y),
-              vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act);
+              reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
+              vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
     return vv_launch_status();
+}
+
+VV_EXPORT int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                        int batch, int side, int cin, int cout, int act, int dtype, void *stream) {
+    return vv_conv3d_k4s2_direct_fwd_io(x, w_packed, scale, shift, y, batch, side, cin, cout, act, dtype, dtype, stream);
 }

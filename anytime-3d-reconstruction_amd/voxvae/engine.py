@@ -242,10 +242,10 @@ class EncoderEngine(_EngineBase):
                            L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
                 hdt = odt
             elif not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
-                o = self._empty(B, side // 2, side // 2, side // 2, f[i])
-                self._call(name, 'vv_conv3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
-                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
-                hdt = self.dt
+                o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
+                self._call(name, 'vv_conv3d_k4s2_direct_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, odt, st)
+                hdt = odt
             else:
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
                 ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], self.dt))

@@ -575,3 +575,22 @@ def test_dense_and_convert_fp8(L):
     want = torch.from_numpy(np.clip(v, -448, 448)).to(F8).float().numpy()
     assert np.array_equal(back.cpu().numpy(), want)
     assert np.array_equal(o8.float().cpu().numpy(), want)
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+def test_conv3d_direct_fp8_output(L):
+    """The direct 64 -> 128 kernel storing e4m3fn instead of bf16 (hand-over into the fp8 layers): equals its own bf16
+    output rounded once more, up to double rounding (bf16 first, then fp8: at most one fp8 ulp apart)."""
+    rng = np.random.default_rng(3)
+    B, side, cin, cout = 2, 16, 64, 128
+    x = _bf16_round(rng.standard_normal((B, side, side, side, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cin, cout)) / np.sqrt(64 * cin)).astype(np.float32))
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
+    xd, sd, hd = _dev(x, torch.bfloat16), _dev(scale), _dev(shift)
+    wp = torch.empty(cout, 64 * cin, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(_dev(w)), L.ptr(wp), cin, cout, L.VV_BF16, _st())
+    y8 = torch.zeros(B, 8, 8, 8, cout, dtype=F8, device=DEV)
+    L.call('vv_conv3d_k4s2_direct_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y8), B, side, cin, cout, 1, L.VV_BF16, L.VV_FP8, _st())
+    torch.cuda.synchronize()
+    _check_fp8_out(y8, ref, 'conv3d direct bf16->fp8')
