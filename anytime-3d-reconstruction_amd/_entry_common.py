@@ -36,7 +36,8 @@ def parse(description, train=False):
     ap.add_argument('--voxel', type=int, default=32, help='voxel side (the reference ships 64; BASELINE.json asks for 32)')
     ap.add_argument('--latent', type=int, default=64)
     ap.add_argument('--batch', type=int, default=64 if train else 72)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'] + ([] if train else ['fp8']),
+                    help="'f32': the reference's arithmetic; 'bf16'; 'fp8' (test_* scripts only: e4m3fn MFMA layers, inference)")
     ap.add_argument('--load-path', default=None)
     ap.add_argument('--save-path', default=None)
     ap.add_argument('--max-iter', type=int, default=None, help='stop after this many iterations (smoke runs)')

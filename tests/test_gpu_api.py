@@ -79,6 +79,25 @@ def test_getLatent_and_bf16_api():
     assert abs(float(out[1]) - g2['p0_scalars'][0]) < 0.02 * g2['p0_scalars'][0]
 
 
+def test_fp8_inference_mode_api():
+    """BASELINE config 5's arithmetic through the model classes: 'fp8' runs the Cin % 128 == 0 MFMA layers on e4m3fn
+    operands (per-channel weight scales), the two-pass missing-modality evaluation included; fit() refuses (inference
+    mode); switching the default back leaves other models untouched."""
+    g, _, m8, d = _model('vae_d32_l64_b2', 'fp8')
+    assert m8._enc_eng.fp8 and m8._dec_eng.fp8
+    x = d['x']
+    out = m8.getEval(inputs=(x, x, d['oh']), category_vectors=d['cats'], missing_prob=0.5, _eps=d['eps'], _mask=d['mask'], _eps2=d['eps2'])
+    ref = g['p5_scalars']
+    sc = np.array([float(v) for v in out[1:5]] + [float(v) for v in out[6:10]])
+    np.testing.assert_allclose(sc[[0, 4]], ref[[0, 4]], rtol=0.03)               # shape losses (fp8 operands: 3 mantissa bits)
+    np.testing.assert_allclose(sc[[1, 2, 5, 6]], ref[[1, 2, 5, 6]], atol=0.02)   # precision / recall
+    pk = m8._enc_eng.packed
+    assert pk.get('q2') and pk.get('q3') and pk.get('q4') and not pk.get('q1')   # E3, E4, E5 fp8; E2 (Cin 64) bf16
+    assert m8._dec_eng.packed.get('q1') and m8._dec_eng.packed.get('q2')
+    with pytest.raises(ValueError):
+        m8.fit((x, x))
+
+
 def test_builders_and_checkpoints(tmp_path):
     import voxvae
     voxvae.set_default_dtype('f32')
