@@ -212,48 +212,87 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     dgamma[c] = (float)ss;
 }
 
-// y = act(x*scale + shift); nv = number of V-element vectors (C % V == 0)
+// y = act(x*scale + shift).  A thread owns V consecutive channels for the whole sweep and walks rows: the per-channel
+// vectors are loaded once per thread (the element-wise form re-read them for every vector: 12 parameter loads next to the
+// 2 payload loads of the backward kernel, which held it at 4.2 TB/s), four rows in flight per trip.
 template <typename T>
-__global__ void bn_act_fwd_kernel(const T *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
-                                  T *__restrict__ y, long nv, int C, int act) {
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T *__restrict__ x, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, T *__restrict__ y, long R, int C, int act) {
     constexpr int V = BnVec<T>::V;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * V) % C);
-        float v[V], sc[V], sh[V], o[V];
-        ldv<T>(x, i, v);
-        ldp<V>(scale, c, sc);
-        ldp<V>(shift, c, sh);
+    const int cvn = C / V, rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
+    const int cv = threadIdx.x % cvn, rsub = threadIdx.x / cvn;
+    if (rsub >= rows_par) return;
+    float sc[V], sh[V];
+    ldp<V>(scale, cv * V, sc);
+    ldp<V>(shift, cv * V, sh);
+    const long stride = (long)gridDim.x * rows_par;
+    long r = (long)blockIdx.x * rows_par + rsub;
+    for (; r + 3 * stride < R; r += 4 * stride) {
+        float v[4][V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ldv<T>(x + (r + k * stride) * C, cv, v[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = vv_apply_act(v[k][e] * sc[e] + sh[e], act);
+            stv<T>(y + (r + k * stride) * C, cv, o);
+        }
+    }
+    for (; r < R; r += stride) {
+        float v[V], o[V];
+        ldv<T>(x + r * C, cv, v);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = vv_apply_act(v[e] * sc[e] + sh[e], act);
-        stv<T>(y, i, o);
+        stv<T>(y + r * C, cv, o);
     }
 }
 
-// dx = gamma*rstd * (du - dbeta/R - xhat*dgamma/R),  du = dy*act'(x*scale+shift)
+// dx = gamma*rstd * (du - dbeta/R - xhat*dgamma/R),  du = dy*act'(x*scale+shift); same thread layout, with the per-channel
+// constants folded to five: dx = sc * (du - k1 - (x - mu) * k2), k1 = dbeta/R, k2 = dgamma*rstd/R.
 template <typename T>
-__global__ void bn_act_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ scale,
-                                  const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
-                                  const float *__restrict__ dgamma, const float *__restrict__ dbeta, T *__restrict__ dx,
-                                  long nv, int C, float invR, int act) {
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, const float *__restrict__ dgamma,
+                                                         const float *__restrict__ dbeta, T *__restrict__ dx, long R, int C, float invR, int act) {
     constexpr int V = BnVec<T>::V;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * V) % C);
-        float v[V], g[V], sc[V], sh[V], mu[V], rs[V], dg[V], db[V], o[V];
-        ldv<T>(x, i, v);
-        ldv<T>(dy, i, g);
-        ldp<V>(scale, c, sc);
-        ldp<V>(shift, c, sh);
-        ldp<V>(mean, c, mu);
-        ldp<V>(rstd, c, rs);
-        ldp<V>(dgamma, c, dg);
-        ldp<V>(dbeta, c, db);
+    const int cvn = C / V, rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
+    const int cv = threadIdx.x % cvn, rsub = threadIdx.x / cvn;
+    if (rsub >= rows_par) return;
+    float sc[V], sh[V], mu[V], k1[V], k2[V];
+    {
+        float rs[V], dg[V], db[V];
+        ldp<V>(scale, cv * V, sc);
+        ldp<V>(shift, cv * V, sh);
+        ldp<V>(mean, cv * V, mu);
+        ldp<V>(rstd, cv * V, rs);
+        ldp<V>(dgamma, cv * V, dg);
+        ldp<V>(dbeta, cv * V, db);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { k1[e] = db[e] * invR; k2[e] = dg[e] * invR * rs[e]; }
+    }
+    auto one = [&](const float (&v)[V], const float (&g)[V], float (&o)[V]) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float d = g[e] * bn_act_grad<T>(v[e] * sc[e] + sh[e], act);
-            const float xh = (v[e] - mu[e]) * rs[e];
-            o[e] = sc[e] * (d - db[e] * invR - xh * dg[e] * invR);
+            o[e] = sc[e] * (d - k1[e] - (v[e] - mu[e]) * k2[e]);
         }
-        stv<T>(dx, i, o);
+    };
+    const long stride = (long)gridDim.x * rows_par;
+    long r = (long)blockIdx.x * rows_par + rsub;
+    for (; r + stride < R; r += 2 * stride) {
+        float v[2][V], g[2][V], o[V];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { ldv<T>(x + (r + k * stride) * C, cv, v[k]); ldv<T>(dy + (r + k * stride) * C, cv, g[k]); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { one(v[k], g[k], o); stv<T>(dx + (r + k * stride) * C, cv, o); }
+    }
+    for (; r < R; r += stride) {
+        float v[V], g[V], o[V];
+        ldv<T>(x + r * C, cv, v);
+        ldv<T>(dy + r * C, cv, g);
+        one(v, g, o);
+        stv<T>(dx + r * C, cv, o);
     }
 }
 
@@ -737,6 +776,15 @@ inline bool bn_shape_ok(long rows, int channels, int dtype) {
     return channels / V >= 64 || 256 % (channels / V) == 0;
 }
 
+// Grid of the two element-wise sweeps: a block covers 256 / (C / V) rows per step; enough blocks for ~4 steps each, at
+// most 8 workgroups per CU's worth
+inline int bn_sweep_blocks(long R, int C, int V) {
+    const int cvn = C / V;
+    const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
+    long nb = (R + 4L * rows_par - 1) / (4L * rows_par);
+    return (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+}
+
 inline int bn_blocks(long R, int C, int V = 4) {
     const int cvn = C / V;
     const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
@@ -777,15 +825,15 @@ VV_EXPORT int vv_bn_act_fwd(const void *x, const float *scale, const float *shif
                             int dtype, void *stream) {
     if (!x || !scale || !shift || !y) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
-    if (rows <= 0 || channels <= 0 || channels % (dtype == VV_BF16 ? 8 : 4)) return VV_ERR_SHAPE;
-    const long n4 = rows * channels / (dtype == VV_BF16 ? 8 : 4);
+    if (!bn_shape_ok(rows, channels, dtype)) return VV_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = bn_sweep_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);
     if (dtype == VV_BF16)
-        VV_LAUNCH(bn_act_fwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), scale, shift,
-                  reinterpret_cast<__bf16 *>(y), n4, channels, act);
+        VV_LAUNCH(bn_act_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16 *>(x), scale, shift,
+                  reinterpret_cast<__bf16 *>(y), rows, channels, act);
     else
-        VV_LAUNCH(bn_act_fwd_kernel<float>, dim3(grid_1d(n4)), dim3(256), 0, st, reinterpret_cast<const float *>(x), scale, shift,
-                  reinterpret_cast<float *>(y), n4, channels, act);
+        VV_LAUNCH(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float *>(x), scale, shift,
+                  reinterpret_cast<float *>(y), rows, channels, act);
     return vv_launch_status();
 }
 
@@ -800,19 +848,19 @@ VV_EXPORT int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, c
     const int nb = bn_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);     // <= the float32 count the workspace is sized for
     const int rpb = (int)((rows + nb - 1) / nb);
     float *part = reinterpret_cast<float *>(workspace);
-    const long n4 = rows * channels / (dtype == VV_BF16 ? 8 : 4);
+    const int sweep = bn_sweep_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);
     if (dtype == VV_BF16) {
         const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *dyb = reinterpret_cast<const __bf16 *>(dy);
         VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
         VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
-        VV_LAUNCH(bn_act_bwd_kernel<__bf16>, dim3(grid_1d(n4)), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, dgamma, dbeta,
-                  reinterpret_cast<__bf16 *>(dx), n4, channels, 1.0f / (float)rows, act);
+        VV_LAUNCH(bn_act_bwd_kernel<__bf16>, dim3(sweep), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, dgamma, dbeta,
+                  reinterpret_cast<__bf16 *>(dx), rows, channels, 1.0f / (float)rows, act);
     } else {
         const float *xf = reinterpret_cast<const float *>(x), *dyf = reinterpret_cast<const float *>(dy);
         VV_LAUNCH((bn_reduce_kernel<1, float>), dim3(nb), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, part, rows, channels, rpb, act);
         VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
-        VV_LAUNCH(bn_act_bwd_kernel<float>, dim3(grid_1d(n4)), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, dgamma, dbeta,
-                  reinterpret_cast<float *>(dx), n4, channels, 1.0f / (float)rows, act);
+        VV_LAUNCH(bn_act_bwd_kernel<float>, dim3(sweep), dim3(256), 0, st, xf, dyf, scale, shift, mean, rstd, dgamma, dbeta,
+                  reinterpret_cast<float *>(dx), rows, channels, 1.0f / (float)rows, act);
     }
     return vv_launch_status();
 }
