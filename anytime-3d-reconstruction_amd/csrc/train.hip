@@ -225,8 +225,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T *__restrict__ x
     float sc[V], sh[V];
     ldp<V>(scale, cv * V, sc);
     ldp<V>(shift, cv * V, sh);
-    const long stride = (long)gridDim.x * rows_par;
-    long r = (long)blockIdx.x * rows_par + rsub;
+    // a block sweeps one contiguous row range (DRAM pages stay local), rows_par rows per step
+    const long rpb = ((R + gridDim.x - 1) / gridDim.x + rows_par - 1) / rows_par * rows_par;
+    const long rend = (blockIdx.x + 1) * rpb < R ? (blockIdx.x + 1) * rpb : R;
+    R = rend;
+    const long stride = rows_par;
+    long r = (long)blockIdx.x * rpb + rsub;
     for (; r + 3 * stride < R; r += 4 * stride) {
         float v[4][V];
 #pragma unroll
@@ -278,8 +282,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T *__restrict__ x
             o[e] = sc[e] * (d - k1[e] - (v[e] - mu[e]) * k2[e]);
         }
     };
-    const long stride = (long)gridDim.x * rows_par;
-    long r = (long)blockIdx.x * rows_par + rsub;
+    const long rpb = ((R + gridDim.x - 1) / gridDim.x + rows_par - 1) / rows_par * rows_par;   // contiguous row range per block
+    const long rend = (blockIdx.x + 1) * rpb < R ? (blockIdx.x + 1) * rpb : R;
+    R = rend;
+    const long stride = rows_par;
+    long r = (long)blockIdx.x * rpb + rsub;
     for (; r + stride < R; r += 2 * stride) {
         float v[2][V], g[2][V], o[V];
 #pragma unroll
@@ -776,13 +783,13 @@ inline bool bn_shape_ok(long rows, int channels, int dtype) {
     return channels / V >= 64 || 256 % (channels / V) == 0;
 }
 
-// Grid of the two element-wise sweeps: a block covers 256 / (C / V) rows per step; enough blocks for ~4 steps each, at
-// most 8 workgroups per CU's worth
+// Grid of the two element-wise sweeps: a block covers 256 / (C / V) rows per step; two steps per block on the short
+// layers, at most 4096 blocks (16 per CU) on the long ones
 inline int bn_sweep_blocks(long R, int C, int V) {
     const int cvn = C / V;
     const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
-    long nb = (R + 4L * rows_par - 1) / (4L * rows_par);
-    return (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+    long nb = (R + 2L * rows_par - 1) / (2L * rows_par);
+    return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
 }
 
 inline int bn_blocks(long R, int C, int V = 4) {
