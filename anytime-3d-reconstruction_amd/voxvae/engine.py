@@ -68,6 +68,17 @@ class _Workspace:
         return self.buf
 
 
+def quant_fp8(w, cout_axis):
+    """Per-output-channel scaling ahead of the fp8 pack: returns (w / s, s) with s = max|w| / 256 per channel (e4m3fn holds
+    +-448; its relative precision does not depend on the scale, its range and subnormal floor do).  The caller folds s into
+    the per-channel scale vector the epilogue applies."""
+    red = [d for d in range(w.dim()) if d != cout_axis]
+    s = w.abs().amax(dim=red).clamp_min(1e-20) / 256.0
+    shape = [1] * w.dim()
+    shape[cout_axis] = -1
+    return (w / s.view(shape)).contiguous(), s.contiguous()
+
+
 class _EngineBase:
     def __init__(self, structure, dtype, device):
         _require_gpu()
@@ -125,13 +136,7 @@ class _EngineBase:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def _quant_fp8(self, w, cout_axis):
-        """Per-output-channel scaling ahead of the fp8 pack: (w / s, s) with s = max|w| / 256 per channel (e4m3fn holds
-        +-448; relative precision does not depend on the scale, the range does)."""
-        red = [d for d in range(w.dim()) if d != cout_axis]
-        s = w.abs().amax(dim=red).clamp_min(1e-20) / 256.0
-        shape = [1] * w.dim()
-        shape[cout_axis] = -1
-        return (w / s.view(shape)).contiguous(), s.contiguous()
+        return quant_fp8(w, cout_axis)
 
     def _as_fp8(self, h, label):
         """bf16 activation -> fp8 copy (the hand-over from a bf16-only layer into an fp8 stretch)."""

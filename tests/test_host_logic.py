@@ -176,3 +176,23 @@ def test_pascal_synthetic_loader_contract():
     assert ld.epoch == 1 and ld.dataLength == 10
     with pytest.raises(FileNotFoundError):
         pascal3D.dataLoaderSingleObject(Pascal3DDataPath='/nonexistent')
+
+
+def test_fp8_weight_quantisation_host_side():
+    """'fp8' inference mode, host side (voxvae/engine.py:quant_fp8): per-output-channel scales keep every channel inside
+    e4m3fn's range whatever its magnitude, and w ~= fp8(w / s) * s to 3 mantissa bits.  No GPU involved (the import of the
+    engine module must not need one either)."""
+    if not hasattr(torch, 'float8_e4m3fn'):
+        pytest.skip('torch.float8_e4m3fn not available')
+    from voxvae import engine as E
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy((rng.standard_normal((4, 4, 4, 8, 16)) * np.exp(rng.uniform(-8, 8, 16))).astype(np.float32))   # Keras conv layout, cout last
+    wq, s = E.quant_fp8(w, 4)
+    assert wq.shape == w.shape and s.shape == (16,)
+    assert float(wq.abs().amax()) <= 256.0 + 1e-3 and torch.allclose(wq.abs().amax(dim=(0, 1, 2, 3)), torch.full((16,), 256.0), rtol=1e-5)
+    back = wq.to(torch.float8_e4m3fn).float() * s
+    big = w.abs() > w.abs().amax(dim=(0, 1, 2, 3), keepdim=True) * 2.0 ** -6          # above the subnormal floor of the scaled channel
+    assert float(((back - w).abs() / w.abs())[big].max()) <= 2.0 ** -4 + 1e-6
+    wt = w.permute(0, 1, 2, 4, 3).contiguous()                                        # transposed-conv layout: cout at axis 3
+    wq2, s2 = E.quant_fp8(wt, 3)
+    assert torch.equal(s2, s) and torch.equal(wq2, wq.permute(0, 1, 2, 4, 3))
