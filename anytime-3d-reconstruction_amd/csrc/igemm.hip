@@ -51,6 +51,8 @@ struct IgemmArgs {
     unsigned a_bytes, w_bytes;  // operand sizes for the buffer descriptors (out-of-range lanes read zeros)
     int nsplit, nparity;  // split-K shares and output-parity panels (both folded into the 1-D grid)
     int pos_major;     // conv modes: GEMM row m = position * batch + sample (tiles share a position -> padded taps skipped)
+    int pair;          // MODE_CONV with 64-byte voxel rows (fp8, Cin 64): a staged 128-byte row = the taps (tw, tw+1), tw even --
+                       // two voxels adjacent in memory; the tap list holds pair indices, validity is per 64-byte half
 };
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -276,7 +278,14 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
         if ((unsigned)mine) atomicOr(&mw[0], (unsigned)mine);
         if ((unsigned)(mine >> 32)) atomicOr(&mw[1], (unsigned)(mine >> 32));
         __syncthreads();
-        const unsigned long long tapmask = ((unsigned long long)mw[1] << 32) | mw[0];
+        unsigned long long tapmask = ((unsigned long long)mw[1] << 32) | mw[0];
+        if (MODE == MODE_CONV && a.pair) {
+            // pair p = taps (2p, 2p+1): listed if either tap is live; entries are pair indices
+            const unsigned long long e = (tapmask | (tapmask >> 1)) & 0x5555555555555555ull;
+            unsigned long long packed = 0ull;
+            for (int q = 0; q < 32; ++q) packed |= ((e >> (2 * q)) & 1ull) << q;
+            tapmask = packed;
+        }
         if (tid < 64 && ((tapmask >> tid) & 1ull)) taplist[__builtin_popcountll(tapmask & ((1ull << tid) - 1ull))] = tid;
         __syncthreads();
         const int ntap = __builtin_amdgcn_readfirstlane(__builtin_popcountll(tapmask));
@@ -296,7 +305,10 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
             kc = (tap << a.cpt_log2) + sub;
             const int li = a.din_log2;
             int toff;
-            if (MODE == MODE_CONV) toff = ((((tap >> 4) << li) + ((tap >> 2) & 3)) << li) + (tap & 3);
+            if (MODE == MODE_CONV) {
+                if (a.pair) tap *= 2;                      // first tap of the pair; the lane's own tap is tap + (slot >> 2)
+                toff = ((((tap >> 4) << li) + ((tap >> 2) & 3)) << li) + (tap & 3);
+            }
             else toff = -(((((tap >> 2) << li) + ((tap >> 1) & 1)) << li) + (tap & 1));
             delta = (toff * a.cin + sub * BK) * (int)sizeof(T);
         } else {
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(256 * KH) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             bool v;
-            if constexpr (MODE == MODE_CONV) v = (rmask[i] >> tap) & 1ull;
+            if constexpr (MODE == MODE_CONV) v = (rmask[i] >> (a.pair ? tap + (gchunk >> 2) : tap)) & 1ull;
             else v = ((unsigned)rmask[i] >> tap) & 1u;
             const unsigned vo = (v && kin) ? (unsigned)(aoff[i] + delta) : OOB;
             vv_dma16(rsA, vo, 0u, lds0 + buf * BM * ROWB + (wave * 8 + 32 * i) * ROWB);
@@ -733,7 +745,10 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     if (M <= 0 || N <= 0 || K <= 0 || N % (out_dtype == VV_BF16 ? 8 : (out_dtype == VV_FP8 ? 16 : 4))) return VV_ERR_SHAPE;
     if (mode == MODE_DENSE ? (K % (bk / 8)) != 0 : (K % bk) != 0) return VV_ERR_SHAPE;
     if (mode == MODE_FIRST && (!vv_is_pow2(din) || cin != 1)) return VV_ERR_SHAPE;
-    if ((mode == MODE_CONV || mode == MODE_CONVT) && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
+    // fp8 with Cin = 64 (64-byte voxel rows): a 128-byte staged row is a pair of w-adjacent taps (stride-2 conv only)
+    const bool pair = mode == MODE_CONV && dtype == VV_FP8 && cin == 64;
+    if ((mode == MODE_CONV || mode == MODE_CONVT) && !pair && (!vv_is_pow2(din) || cin % bk || !vv_is_pow2(cin / bk))) return VV_ERR_SHAPE;
+    if (pair && !vv_is_pow2(din)) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const Plan p = make_plan(mode, M, N, K, dtype);
     const size_t a_bytes = mode == MODE_DENSE ? (size_t)M * K * vv_dtype_size(dtype)
@@ -747,7 +762,8 @@ int run_igemm(int mode, const void *x, const void *w, const float *scale, const 
     a.M = M; a.N = N; a.K = K;
     a.din_log2 = mode == MODE_DENSE ? 0 : vv_log2(din);
     a.cin = cin;
-    a.cpt_log2 = (mode == MODE_DENSE || mode == MODE_FIRST) ? 0 : vv_log2(cin / bk);
+    a.cpt_log2 = (mode == MODE_DENSE || mode == MODE_FIRST || pair) ? 0 : vv_log2(cin / bk);
+    a.pair = pair ? 1 : 0;
     a.nchunks = (K + bk - 1) / bk;
     a.chunks_per_split = p.cps;
     a.act = act;

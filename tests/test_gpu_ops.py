@@ -479,7 +479,8 @@ def _check_fp8_out(got_f8, ref, what):
 
 
 @pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
-@pytest.mark.parametrize('B,side,cin,cout,odt', [(2, 8, 128, 256, 'bf16'), (2, 8, 128, 256, 'fp8'), (37, 4, 256, 512, 'fp8'), (1, 16, 128, 64, 'f32')])
+@pytest.mark.parametrize('B,side,cin,cout,odt', [(2, 8, 128, 256, 'bf16'), (2, 8, 128, 256, 'fp8'), (37, 4, 256, 512, 'fp8'), (1, 16, 128, 64, 'f32'),
+                                                 (2, 16, 64, 128, 'fp8'), (3, 8, 64, 128, 'bf16'), (33, 4, 64, 64, 'fp8')])   # Cin 64: tap-pair rows
 def test_conv3d_k4s2_fp8(L, B, side, cin, cout, odt):
     """Stride-2 Conv3D on the fp8 MFMA (operands e4m3fn, float32 accumulation, per-channel scales in `scale`) against the
     float64 definition on the same fp8-representable operands; outputs bf16 / fp8 / f32."""
@@ -506,8 +507,8 @@ def test_conv3d_k4s2_fp8(L, B, side, cin, cout, odt):
         _check_fp8_out(y, ref, 'conv3d fp8->fp8')
     else:
         _check(y, ref, odt, 'conv3d fp8->' + odt)
-    # cin not a multiple of 128 has no fp8 form
-    assert L.load().vv_conv3d_k4s2_fwd_io(L.ptr(xd), L.ptr(wp), None, None, L.ptr(y), B, side, 64, cout, 0, L.VV_FP8, L.DTYPES[odt],
+    # Cin must be 64 (tap-pair rows) or a multiple of 128
+    assert L.load().vv_conv3d_k4s2_fwd_io(L.ptr(xd), L.ptr(wp), None, None, L.ptr(y), B, side, 32, cout, 0, L.VV_FP8, L.DTYPES[odt],
                                           L.ptr(ws), ws.numel(), _st()) == -2
 
 
