@@ -536,11 +536,11 @@ __global__ __launch_bounds__(256) void first_conv_bf16_kernel(const float *__res
 // (k = 16 td + 8 fh + j  <->  th = 2 fh + (j>>2), tw = j&3) is two 8-byte LDS reads, and no im2col tile is ever written.
 // Weights (64 x 64 taps) live in registers as A fragments for the whole persistent loop; the next item's planes are in
 // flight (registers) while the current item multiplies, transposes through LDS and stores its contiguous 32 KiB.
-template <int NI>
+template <int NI, bool OUT8>       // OUT8: store e4m3fn (64-byte rows) for an fp8 second layer instead of bf16
 __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp,
                                                                const float *__restrict__ scale, const float *__restrict__ shift,
-                                                               __bf16 *__restrict__ y, int batch, int din_log2, int act, int items_per_wg) {
-    constexpr int COUT = 64, EPITCH = COUT * 2;            // output rows are 8 chunks of 16 B, chunk ^ (row & 7)
+                                                               void *__restrict__ y, int batch, int din_log2, int act, int items_per_wg) {
+    constexpr int COUT = 64, EPITCH = COUT * 2;            // output rows are 8 chunks of 16 B, chunk ^ (row & 7); fp8: 4 chunks, chunk ^ (row & 3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -640,24 +640,40 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                 for (int g = 0; g < 4; ++g) {
                     const int c = nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
-                    bf16x4 ov;
+                    f32x4 tv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[nt][4 * g + e] * sc[e] + sh[e];
                         if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
                         else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                         else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                        ov[e] = static_cast<__bf16>(t);
+                        tv[e] = t;
                     }
-                    *reinterpret_cast<bf16x4 *>(stage + o * EPITCH + ((((c >> 3) ^ o) & 7) << 4) + (c & 4) * 2) = ov;
+                    if constexpr (OUT8) {                  // e4m3fn for an fp8 second layer: 64-byte rows
+                        *reinterpret_cast<unsigned *>(stage + o * EPITCH + ((((c >> 4) ^ o) & 3) << 4) + (c & 12)) = vv_pack_fp8x4(tv);
+                    } else {
+                        bf16x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = static_cast<__bf16>(tv[e]);
+                        *reinterpret_cast<bf16x4 *>(stage + o * EPITCH + ((((c >> 3) ^ o) & 7) << 4) + (c & 4) * 2) = ov;
+                    }
                 }
         }
         __syncthreads();
-        char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2);     // the item's 256 outputs are contiguous in y
+        if constexpr (OUT8) {
+            char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i, rl = idx >> 3, c = idx & 7;
-            *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 7) << 4));
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i, rl = idx >> 2, c = idx & 3;
+                *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 3) << 4));
+            }
+        } else {
+            char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2);     // the item's 256 outputs are contiguous in y
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i, rl = idx >> 3, c = idx & 7;
+                *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 7) << 4));
+            }
         }
     }
     };
@@ -729,9 +745,10 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
 
 // bf16 fast path of vv_conv3d_first_fwd (igemm.hip dispatches here): w_packed = vv_pack_conv_k4(cin = 1) = [64][64] bf16.
 int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,
-                              int side, int act, void *stream) {
+                              int side, int act, void *stream, int out_fp8) {
     const int li = vv_log2(side);
-    if (side >= 32 && side <= 256 && !getenv("VV_FIRSTCONV_GATHER")) {
+    if (out_fp8 && !(side >= 32 && side <= 256)) return VV_ERR_DTYPE;      // only the plane-form kernel stores e4m3fn
+    if (side >= 32 && side <= 256 && (out_fp8 || !getenv("VV_FIRSTCONV_GATHER"))) {
         const int ow = side / 2, oh = 256 / ow, r = 2 * oh + 2, pd = side / 2 + 2;
         const long nitems = (long)batch * ow * (ow / oh);
         const size_t lds = (((size_t)4 * r * pd * 4 + 15) & ~(size_t)15) + 256 * (64 * 2) + 128 * sizeof(float) + 8 * 64 * 16;
@@ -740,12 +757,14 @@ int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float 
         const int ipw = (int)((nitems + maxwg - 1) / maxwg);
         const int grid = (int)((nitems + ipw - 1) / ipw);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        if (ni <= 5)
-            VV_LAUNCH((first_conv_plane_kernel<5>), dim3(grid), dim3(256), lds, st, x, reinterpret_cast<const __bf16 *>(w_packed), scale, shift,
-                      reinterpret_cast<__bf16 *>(y), batch, li, act, ipw);
-        else
-            VV_LAUNCH((first_conv_plane_kernel<6>), dim3(grid), dim3(256), lds, st, x, reinterpret_cast<const __bf16 *>(w_packed), scale, shift,
-                      reinterpret_cast<__bf16 *>(y), batch, li, act, ipw);
+        const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
+        if (ni <= 5) {
+            if (out_fp8) VV_LAUNCH((first_conv_plane_kernel<5, true>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
+            else VV_LAUNCH((first_conv_plane_kernel<5, false>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
+        } else {
+            if (out_fp8) VV_LAUNCH((first_conv_plane_kernel<6, true>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
+            else VV_LAUNCH((first_conv_plane_kernel<6, false>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
+        }
         return vv_launch_status();
     }
     const long M = (long)batch << (3 * (li - 1));

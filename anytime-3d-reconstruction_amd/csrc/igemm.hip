@@ -26,7 +26,7 @@
 #include "common.h"
 
 int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,
-                              int side, int act, void *stream);   // first_last.hip
+                              int side, int act, void *stream, int out_fp8);   // first_last.hip
 
 namespace {
 
@@ -851,13 +851,25 @@ VV_EXPORT int vv_dense_fwd(const void *x, const void *w_packed, const float *sca
 }
 
 // Cin = 1 first layer on the same MFMA tile engine: w_packed = vv_pack_conv_k4(cin = 1) = [Cout][64 taps].
-VV_EXPORT int vv_conv3d_first_fwd(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
-                                  int batch, int side, int cout, int act, int dtype, void *stream) {
+VV_EXPORT int vv_conv3d_first_fwd_io(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                     int batch, int side, int cout, int act, int dtype, int out_dtype, void *stream) {
     if (batch <= 0 || side < 2 || !vv_is_pow2(side)) return VV_ERR_SHAPE;
     if ((long)batch * side * side * side >= (1L << 31)) return VV_ERR_SHAPE;
     const int o = side / 2;
+    if (out_dtype == VV_FP8) {                  // e4m3fn output: the bf16 plane-form kernel only (side >= 32, Cout 64)
+        if (dtype != VV_BF16 || cout != 64 || side < 32 || side > 256) return VV_ERR_DTYPE;
+        if (!x || !w_packed || !y) return VV_ERR_NULL;
+        if (!vv_aligned16(y) || !vv_aligned16(w_packed)) return VV_ERR_ALIGN;
+        return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream, 1);
+    }
+    if (out_dtype != dtype) return VV_ERR_DTYPE;
     if (dtype == VV_BF16 && cout == 64 && x && w_packed && y && vv_aligned16(y) && vv_aligned16(w_packed) && !getenv("VV_NO_FIRSTCONV"))
-        return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream);
+        return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream, 0);
     return run_igemm(MODE_FIRST, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64, side, 1, act, dtype, dtype, nullptr,
                      0, stream, batch);
+}
+
+VV_EXPORT int vv_conv3d_first_fwd(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                  int batch, int side, int cout, int act, int dtype, void *stream) {
+    return vv_conv3d_first_fwd_io(x, w_packed, scale, shift, y, batch, side, cout, act, dtype, dtype, stream);
 }

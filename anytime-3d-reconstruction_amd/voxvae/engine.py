@@ -201,7 +201,8 @@ class EncoderEngine(_EngineBase):
         self.packed['w0'] = self._empty(f[0], 64)
         L.call('vv_pack_conv_k4', L.ptr(p['conv0/kernel']), L.ptr(self.packed['w0']), 1, f[0], self.dt, st)
         for i in range(1, len(f) - 1):
-            q = self.fp8 and f[i - 1] % 128 == 0
+            # Cin 64 (the second layer) has an fp8 form too (tap-pair rows); VV_FP8_E2=0 keeps it on the bf16 direct kernel
+            q = self.fp8 and (f[i - 1] % 128 == 0 or (f[i - 1] == 64 and os.environ.get('VV_FP8_E2', '1') != '0'))
             wk = p['conv%d/kernel' % i]
             if q:
                 wk, qs = self._quant_fp8(wk, 4)
@@ -230,10 +231,12 @@ class EncoderEngine(_EngineBase):
         if tuple(x.shape[1:]) != (D, D, D, 1) or x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError('encoder input must be contiguous float32 [B,%d,%d,%d,1], got %s %s' % (D, D, D, tuple(x.shape), x.dtype))
         side = D // 2
-        h = self._empty(B, side, side, side, f[0])
-        self._call('E1', 'vv_conv3d_first_fwd', L.ptr(x), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
-               L.ptr(h), B, D, f[0], self.act, self.dt, st)
-        hdt = self.dt                                        # element type of h: the engine's dtype, or fp8 inside an fp8 stretch
+        # element type of h: the engine's dtype, or fp8 inside an fp8 stretch (the first layer stores e4m3fn itself when the
+        # second layer is fp8 and its plane-form kernel applies)
+        hdt = L.VV_FP8 if (pk.get('q1', False) and D >= 32 and f[0] == 64 and self.dt == L.VV_BF16) else self.dt
+        h = self._empty(B, side, side, side, f[0], dtype=torch.uint8 if hdt == L.VV_FP8 else None)
+        self._call('E1', 'vv_conv3d_first_fwd_io', L.ptr(x), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']),
+               L.ptr(h), B, D, f[0], self.act, self.dt, hdt, st)
         for i in range(1, len(f) - 1):
             q, nq = pk.get('q%d' % i, False), pk.get('q%d' % (i + 1), False)
             odt = L.VV_FP8 if nq else self.dt

@@ -30,6 +30,7 @@ SIGNATURES = {
     'vv_pack_dense': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_fold_bn': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),
     'vv_conv3d_first_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'vv_conv3d_first_fwd_io': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_conv3d_k4s2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'vv_conv3d_k4s2_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_convT3d_k4s2_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),

@@ -72,6 +72,10 @@ int vv_fold_bn(const float *gamma, const float *beta, const float *mean, const f
  * w_packed = vv_pack_conv_k4(cin = 1) = [Cout][64]; y [B,D/2,D/2,D/2,Cout] dtype. */
 int vv_conv3d_first_fwd(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
                         int batch, int side, int cout, int act, int dtype, void *stream);
+/* Same with a separate output element type: out_dtype VV_FP8 (e4m3fn) is available for dtype VV_BF16, Cout 64, side >= 32
+ * (the hand-over into an fp8 second layer); otherwise out_dtype must equal dtype. */
+int vv_conv3d_first_fwd_io(const float *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                           int batch, int side, int cout, int act, int dtype, int out_dtype, void *stream);
 
 /* conv3DEnc, Cin % 64 == 0: Conv3D k4 s2 SAME + BN + act as an implicit GEMM on MFMA
  * (autoencoder3D.py:26-39).  x [B,D,D,D,Cin]; w = vv_pack_conv_k4; y [B,D/2,...,Cout]. */

@@ -92,7 +92,7 @@ def test_fp8_inference_mode_api():
     np.testing.assert_allclose(sc[[0, 4]], ref[[0, 4]], rtol=0.03)               # shape losses (fp8 operands: 3 mantissa bits)
     np.testing.assert_allclose(sc[[1, 2, 5, 6]], ref[[1, 2, 5, 6]], atol=0.02)   # precision / recall
     pk = m8._enc_eng.packed
-    assert pk.get('q2') and pk.get('q3') and pk.get('q4') and not pk.get('q1')   # E3, E4, E5 fp8; E2 (Cin 64) bf16
+    assert pk.get('q1') and pk.get('q2') and pk.get('q3') and pk.get('q4')       # E2 (Cin 64: tap-pair rows), E3, E4, E5 on fp8 operands
     assert m8._dec_eng.packed.get('q1') and m8._dec_eng.packed.get('q2')
     with pytest.raises(ValueError):
         m8.fit((x, x))
