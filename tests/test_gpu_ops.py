@@ -595,3 +595,23 @@ def test_conv3d_direct_fp8_output(L):
     L.call('vv_conv3d_k4s2_direct_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y8), B, side, cin, cout, 1, L.VV_BF16, L.VV_FP8, _st())
     torch.cuda.synchronize()
     _check_fp8_out(y8, ref, 'conv3d direct bf16->fp8')
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,D', [(2, 32), (1, 64)])
+def test_conv3d_first_fp8_output(L, B, D):
+    """First layer (plane-form kernel) storing e4m3fn for an fp8 second layer; smaller grids have no fp8 store."""
+    from voxvae import synthetic as syn
+    rng = np.random.default_rng(D)
+    x = syn.make_voxels(B, D, seed=D)
+    w = _bf16_round((rng.standard_normal((4, 4, 4, 1, 64)) / 8).astype(np.float32))
+    scale, shift = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(0, 0.3, 64).astype(np.float32)
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu')
+    wp = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(_dev(w)), L.ptr(wp), 1, 64, L.VV_BF16, _st())
+    xd, sd, hd = _dev(x), _dev(scale), _dev(shift)
+    y = torch.zeros(B, D // 2, D // 2, D // 2, 64, dtype=F8, device=DEV)
+    L.call('vv_conv3d_first_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, D, 64, 1, L.VV_BF16, L.VV_FP8, _st())
+    torch.cuda.synchronize()
+    _check_fp8_out(y, ref, 'conv3d_first bf16->fp8')
+    assert L.load().vv_conv3d_first_fwd_io(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, 16, 64, 1, L.VV_BF16, L.VV_FP8, _st()) == -3   # VV_ERR_DTYPE
