@@ -320,18 +320,25 @@ class DecoderEngine(_EngineBase):
         pk['w0'] = self._empty(S3 * f[0], lin)
         L.call('vv_pack_convT_k4s1_dense', L.ptr(p['convT0/kernel']), L.ptr(pk['w0']), self.S, self.ch, f[0], self.dt, st)
         pk['scale0'], pk['shift0'] = self._fold('bnT0', f[0], S3)
-        # fp8 mode: the stride-2 layers with Cin % 128 == 0 run on fp8 operands; the last of them (128 -> 64) only when
-        # VV_FP8_LAST is set -- its bf16 direct kernel is faster than the fp8 implicit GEMM (measured)
-        last = len(f) - 2
+        # fp8 mode: the stride-2 layers with Cin % 128 == 0 run on fp8 operands -- the 128 -> 64 layer on the fp8 twin of its
+        # direct kernel (VV_FP8_LAST=igemm: fp8 implicit GEMM, VV_FP8_LAST=0: bf16 direct kernel), the others on the implicit GEMM
         for i in range(1, len(f) - 1):
             side_i = self.S << (i - 1)
             direct = not os.environ.get('VV_NO_DIRECT') and bool(L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt))
-            q = self.fp8 and f[i - 1] % 128 == 0 and not (direct and i == last and not os.environ.get('VV_FP8_LAST'))
+            q = self.fp8 and f[i - 1] % 128 == 0
+            mode = os.environ.get('VV_FP8_LAST', 'direct')
+            direct8 = q and direct and mode not in ('0', 'igemm') and bool(L.load().vv_convT3d_k4s2_direct_fp8_supported(side_i, f[i - 1], f[i]))
+            if q and direct and mode == '0':
+                q = False
             wk = p['convT%d/kernel' % i]
             if q:
                 wk, qs = self._quant_fp8(wk, 3)
-            pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1], dtype=torch.uint8 if q else None)
-            L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(pk['w%d' % i]), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
+            if direct8:
+                pk['wq8f%d' % i] = self._empty(64 * f[i - 1] * f[i], dtype=torch.uint8)
+                L.call('vv_pack_convT_k4s2_frag_fp8', L.ptr(wk), L.ptr(pk['wq8f%d' % i]), f[i - 1], f[i], st)
+            else:
+                pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1], dtype=torch.uint8 if q else None)
+                L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(pk['w%d' % i]), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
             pk['scale%d' % i], pk['shift%d' % i] = self._fold('bnT%d' % i, f[i])
             if q:
                 pk['q%d' % i] = True
@@ -373,6 +380,12 @@ class DecoderEngine(_EngineBase):
                 continue
             if q and hdt != L.VV_FP8:
                 h = self._as_fp8(h, name + 'c')
+            if ('wq8f%d' % i) in pk:                          # fp8 direct kernel: e4m3fn in, bf16 out
+                o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+                self._call(name, 'vv_convT3d_k4s2_direct_fp8_fwd', L.ptr(h), L.ptr(pk['wq8f%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, st)
+                h, side, hdt = o, 2 * side, self.dt
+                continue
             idt = L.VV_FP8 if q else self.dt
             ws = self.ws.get(L.load().vv_convT3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], idt))
             o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i], dtype=torch.uint8 if nq else None)

@@ -122,6 +122,13 @@ int vv_convT3d_k4s2_direct_supported(int side, int cin, int cout, int dtype);
 int vv_pack_convT_k4s2_frag(const float *w_keras, void *packed, int cin, int cout, void *stream);
 int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
                                int batch, int side, int cin, int cout, int act, int dtype, void *stream);
+/* fp8 twin of the direct transposed layer (convt_direct_fp8.hip): x and w_frag in OCP e4m3fn (w_frag from
+ * vv_pack_convT_k4s2_frag_fp8, which converts a float32 Keras kernel already divided by its per-output-channel scale; the
+ * scale belongs in `scale`), block-scaled K = 64 MFMA, y stored as bf16.  Cin 128 -> Cout 64, side >= 8. */
+int vv_convT3d_k4s2_direct_fp8_supported(int side, int cin, int cout);
+int vv_pack_convT_k4s2_frag_fp8(const float *w_keras, void *packed, int cin, int cout, void *stream);
+int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
+                                   int batch, int side, int cin, int cout, int act, void *stream);
 
 /* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
  * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).

@@ -615,3 +615,36 @@ def test_conv3d_first_fp8_output(L, B, D):
     torch.cuda.synchronize()
     _check_fp8_out(y, ref, 'conv3d_first bf16->fp8')
     assert L.load().vv_conv3d_first_fwd_io(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, 16, 64, 1, L.VV_BF16, L.VV_FP8, _st()) == -3   # VV_ERR_DTYPE
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,side,act', [(1, 8, 1), (3, 8, 0), (2, 16, 1), (1, 32, 2)])
+def test_convT3d_direct_fp8(L, B, side, act):
+    """fp8 twin of the direct 128 -> 64 transposed layer (LDS-resident halo tile, K = 64 block-scaled MFMA, bf16 output)
+    against the float64 definition on the same fp8-representable operands, and against the fp8 implicit GEMM."""
+    cin, cout = 128, 64
+    lib = L.load()
+    assert lib.vv_convT3d_k4s2_direct_fp8_supported(side, cin, cout) == 1 and lib.vv_convT3d_k4s2_direct_fp8_supported(4, cin, cout) == 0
+    rng = np.random.default_rng(side + B)
+    x = _fp8_round(rng.standard_normal((B, side, side, side, cin)))
+    w = _fp8_round(rng.standard_normal((4, 4, 4, cout, cin)))
+    scale = (rng.uniform(0.5, 1.5, cout) / np.sqrt(8 * cin)).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    actname = {0: 'none', 1: 'elu', 2: 'relu'}[act]
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, actname)
+    xd, wd, sd, hd = _dev(x).to(F8), _dev(w), _dev(scale), _dev(shift)
+    wf = torch.empty(64 * cin * cout, dtype=torch.uint8, device=DEV)
+    L.call('vv_pack_convT_k4s2_frag_fp8', L.ptr(wd), L.ptr(wf), cin, cout, _st())
+    y = torch.full((B, 2 * side, 2 * side, 2 * side, cout), -7.0, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_direct_fp8_fwd', L.ptr(xd), L.ptr(wf), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, act, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'convT3d_direct_fp8')
+    wp = torch.empty(8, cout, 8 * cin, dtype=F8, device=DEV)
+    L.call('vv_pack_convT_k4s2', L.ptr(wd), L.ptr(wp), cin, cout, L.VV_FP8, _st())
+    ws = torch.empty(max(lib.vv_convT3d_k4s2_workspace_bytes(B, side, cin, cout, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
+    y2 = torch.empty_like(y)
+    L.call('vv_convT3d_k4s2_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y2), B, side, cin, cout, act, L.VV_FP8, L.VV_BF16,
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= 2e-2 * max(1.0, float(np.abs(ref).max())), 'direct vs implicit GEMM (fp8): %.3e' % d
