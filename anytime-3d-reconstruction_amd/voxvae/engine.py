@@ -245,9 +245,15 @@ class EncoderEngine(_EngineBase):
                 if hdt != L.VV_FP8:
                     h = self._as_fp8(h, name + 'c')
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
-                ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], L.VV_FP8))
-                self._call(name, 'vv_conv3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
-                           L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
+                if (not os.environ.get('VV_NO_DIRECT') and os.environ.get('VV_FP8_E2', '1') != 'igemm' and odt != L.VV_F32
+                        and L.load().vv_conv3d_k4s2_direct_fp8_supported(side, f[i - 1], f[i])):
+                    # the widest encoder layer: fp8 twin of its direct kernel, same packed weights as the implicit GEMM
+                    self._call(name, 'vv_conv3d_k4s2_direct_fp8_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]),
+                               L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, odt, st)
+                else:
+                    ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], L.VV_FP8))
+                    self._call(name, 'vv_conv3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
+                               L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
                 hdt = odt
             elif not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)

@@ -40,6 +40,8 @@ SIGNATURES = {
     'vv_conv3d_k4s2_direct_supported': (_i, [_i, _i, _i, _i]),
     'vv_conv3d_k4s2_direct_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_conv3d_k4s2_direct_fwd_io': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'vv_conv3d_k4s2_direct_fp8_supported': (_i, [_i, _i, _i]),
+    'vv_conv3d_k4s2_direct_fp8_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_convT3d_k4s2_direct_supported': (_i, [_i, _i, _i, _i]),
     'vv_pack_convT_k4s2_frag': (_i, [_vp, _vp, _i, _i, _vp]),
     'vv_convT3d_k4s2_direct_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -113,6 +113,12 @@ int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *
 /* Same with the output stored as VV_BF16 or VV_FP8 (e4m3fn: the hand-over to an fp8 layer without a conversion pass). */
 int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
                                  int batch, int side, int cin, int cout, int act, int dtype, int out_dtype, void *stream);
+/* fp8 twin of the direct 64 -> 128 layer (conv_direct_fp8.hip): x and w_packed (vv_pack_conv_k4 with dtype VV_FP8, from a
+ * kernel already divided by its per-output-channel scale; the scale belongs in `scale`) in OCP e4m3fn, block-scaled K = 64
+ * MFMA, y stored as VV_FP8 or VV_BF16.  Input side >= 16. */
+int vv_conv3d_k4s2_direct_fp8_supported(int side, int cin, int cout);
+int vv_conv3d_k4s2_direct_fp8_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,
+                                  int batch, int side, int cin, int cout, int act, int out_dtype, void *stream);
 
 /* Direct variant of vv_convT3d_k4s2_fwd for the widest decoder layer (bf16, Cin 128 -> Cout 64, side >= 8): the input
  * halo tile of a 4x4x8 block of cells is staged in LDS once and serves all 8 parities x 8 taps; weights come from the

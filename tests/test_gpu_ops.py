@@ -648,3 +648,39 @@ def test_convT3d_direct_fp8(L, B, side, act):
     torch.cuda.synchronize()
     d = (y.float() - y2.float()).abs().max().item()
     assert d <= 2e-2 * max(1.0, float(np.abs(ref).max())), 'direct vs implicit GEMM (fp8): %.3e' % d
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,side,act,odt', [(1, 16, 1, 'bf16'), (3, 16, 0, 'fp8'), (2, 32, 1, 'fp8'), (1, 64, 2, 'bf16')])
+def test_conv3d_direct_fp8(L, B, side, act, odt):
+    """fp8 twin of the direct 64 -> 128 layer (phase tiles with 64-byte rows, tap pairs per chunk, K = 64 block-scaled MFMA)
+    against the float64 definition on fp8-representable operands, and against the fp8 implicit GEMM (tap-pair rows)."""
+    cin, cout = 64, 128
+    lib = L.load()
+    assert lib.vv_conv3d_k4s2_direct_fp8_supported(side, cin, cout) == 1 and lib.vv_conv3d_k4s2_direct_fp8_supported(8, cin, cout) == 0
+    rng = np.random.default_rng(side + 3 * B)
+    x = _fp8_round(rng.standard_normal((B, side, side, side, cin)))
+    w = _fp8_round(rng.standard_normal((4, 4, 4, cin, cout)))
+    scale = (rng.uniform(0.5, 1.5, cout) / np.sqrt(64 * cin)).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    actname = {0: 'none', 1: 'elu', 2: 'relu'}[act]
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, actname)
+    xd, sd, hd = _dev(x).to(F8), _dev(scale), _dev(shift)
+    wp = torch.empty(cout, 64 * cin, dtype=F8, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(_dev(w)), L.ptr(wp), cin, cout, L.VV_FP8, _st())
+    so = side // 2
+    tout = {'bf16': torch.bfloat16, 'fp8': F8}[odt]
+    y = torch.zeros(B, so, so, so, cout, dtype=tout, device=DEV)
+    L.call('vv_conv3d_k4s2_direct_fp8_fwd', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, act, L.DTYPES[odt], _st())
+    torch.cuda.synchronize()
+    if odt == 'fp8':
+        _check_fp8_out(y, ref, 'conv3d_direct_fp8 -> fp8')
+    else:
+        _check(y, ref, 'bf16', 'conv3d_direct_fp8 -> bf16')
+    ws = torch.empty(max(lib.vv_conv3d_k4s2_workspace_bytes(B, side, cin, cout, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
+    y2 = torch.zeros(B, so, so, so, cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_conv3d_k4s2_fwd_io', L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y2), B, side, cin, cout, act, L.VV_FP8, L.VV_BF16,
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    d = (y.float() - y2.float()).abs().max().item()
+    assert d <= 0.07 * max(1.0, float(np.abs(ref).max())), 'direct vs implicit GEMM (fp8): %.3e' % d
