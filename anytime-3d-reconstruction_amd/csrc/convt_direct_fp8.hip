@@ -124,8 +124,9 @@ __global__ __launch_bounds__(F8_NW * 64, 1) void convT_direct_fp8_kernel(const u
         const int sw = ((zw >> 1) + 4 * zh) & 7;
         return tile_lds + (((pd - ad + 1) * HH + zh) * HW + zw) * RB + (((ks * 4 + fh * 2) ^ sw) << 4);
     };
-    u32x4 F[MT][2];
-    auto ld = [&](unsigned addr) {
+    // A fragments: two sets, the one of the next k-step in flight while the 8 MFMAs of the current k-step run
+    u32x4 FP[MT][2], FQ[MT][2];
+    auto ld = [&](u32x4 (&F)[MT][2], unsigned addr) {
         const unsigned addr2 = addr ^ 16u;
         asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
                      "ds_read_b128 %2, %8 offset:%10\n\tds_read_b128 %3, %9 offset:%10\n\t"
@@ -135,13 +136,13 @@ __global__ __launch_bounds__(F8_NW * 64, 1) void convT_direct_fp8_kernel(const u
                      : "v"(addr), "v"(addr2), "n"(HH * HW * RB), "n"(2 * HH * HW * RB), "n"(3 * HH * HW * RB)
                      : "memory");
     };
-    auto wait_a = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)"
+    auto wait_a = [&](u32x4 (&F)[MT][2], auto n_c) {       // LDS returns in order: lgkmcnt(8) = all but the 8 reads just issued
+        asm volatile("s_waitcnt lgkmcnt(%8)"
                      : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1])
-                     :
+                     : "n"(decltype(n_c)::value)
                      : "memory");
     };
-    auto mma = [&](const uint4 *bw, int nt) {
+    auto mma = [&](const u32x4 (&F)[MT][2], const uint4 *bw, int nt) {
         const i32x8 wv = {(int)bw[0].x, (int)bw[0].y, (int)bw[0].z, (int)bw[0].w, (int)bw[1].x, (int)bw[1].y, (int)bw[1].z, (int)bw[1].w};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -150,29 +151,31 @@ __global__ __launch_bounds__(F8_NW * 64, 1) void convT_direct_fp8_kernel(const u
             if (nt == 0) acc[mt][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[mt][0], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
             else acc[mt][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[mt][1], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         }
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[mt][0]), "+v"(acc[mt][1]));   // pin the (pure) MFMAs in place: without
+        __builtin_amdgcn_sched_barrier(0);                                                         // this the kernel needs all 256 VGPRs
     };
 
-    // k-step kk = (tap a = kk >> 1, ks = kk & 1) uses groups 2 kk (channel tile 0) and 2 kk + 1 (channel tile 1); the A
-    // fragments of the next k-step are requested right after the last MFMA that reads the current ones was issued
-    ld(a_addr(0, 0));
+    // k-step kk = (tap a = kk >> 1, ks = kk & 1) uses groups 2 kk (channel tile 0) and 2 kk + 1 (channel tile 1)
+    using N8 = std::integral_constant<int, 8>;
+    ld(FP, a_addr(0, 0));
 #pragma unroll 1
     for (int kk = 0; kk < 8 * KS; kk += 2) {
         const int G = 2 * kk;
         load_group(G + 3, b3);
-        wait_a();
-        mma(b0, 0);
+        ld(FQ, a_addr((kk + 1) >> 1, (kk + 1) & 1));
+        wait_a(FP, N8{});
+        mma(FP, b0, 0);
         load_group(G + 4, b0);
-        mma(b1, 1);
-        ld(a_addr((kk + 1) >> 1, (kk + 1) & 1));
+        mma(FP, b1, 1);
         load_group(G + 5, b1);
-        wait_a();
-        mma(b2, 0);
+        ld(FP, a_addr(((kk + 2) >> 1) & 7, kk & 1));       // wraps harmlessly after the last tap
+        wait_a(FQ, N8{});
+        mma(FQ, b2, 0);
         load_group(G + 6, b2);
-        mma(b3, 1);
-        ld(a_addr(((kk + 2) >> 1) & 7, kk & 1));           // wraps harmlessly after the last tap
+        mma(FQ, b3, 1);
     }
-    wait_a();                                              // the wrapped look-ahead read
+    wait_a(FP, std::integral_constant<int, 0>{});          // the wrapped look-ahead read
 
     // ---- epilogue: lane = cell (mt, mh, mw), registers walk channels; folded BN quads fetched as one batch
     f32x4 scv[NT][4], shv[NT][4];
