@@ -32,8 +32,8 @@ PEAK = {'bf16': 2.5e15, 'f32': 157.3e12, 'fp8': 5.0e15}   # dense MFMA peaks, /o
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'])
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--voxel', type=int, default=32)
