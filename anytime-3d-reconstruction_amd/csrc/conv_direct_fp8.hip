@@ -56,11 +56,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_fp8_kernel(const unsigned 
 
     // ---- producers
     auto issue_x = [&](int q, int slot) {            // slot = 0..3: piece slot*8 + wave of phase q into tile[q & 1]
-        // the lane id goes through an opaque move so that this address arithmetic is redone per call: hoisted out of the
-        // phase loop it would pin ~40 registers next to the two 32-register fragment sets (first version: 168 B of spills
-        // inside the loop, 0.142 ms)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        const int ln = lane;
         const int piece = slot * 8 + wave;
         const int rl = piece * 16 + (ln >> 2);
         const int zd = rl / 81, rem = rl - zd * 81, jh = rem / 9, jw = rem - jh * 9;
@@ -74,8 +70,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct_fp8_kernel(const unsigned 
     auto issue_w = [&](int c) {                      // chunk c = q*4 + j (taps a = 2j, 2j+1) into ring[c % 3]: rows 16*wave .. 16*wave+15
         const int q = c >> 2, j = c & 3;
         const unsigned st = lds0 + F8_RING + (c % F8_NST) * F8_WST;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        const int ln = lane;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 8 + (ln >> 3);
