@@ -125,8 +125,9 @@ def test_d64_vae_config_against_c_oracle(dtname, B):
         assert np.array_equal((r['logits'] >= 0)[safe], (c['logits'] >= 0)[safe])
 
 
-def test_full_batch_256_properties_bf16():
-    """BASELINE.json's headline size (B=256, 32^3, bf16): size-independent properties instead of a full oracle run --
+@pytest.mark.parametrize('dtname', ['bf16', 'fp8'])
+def test_full_batch_256_properties(dtname):
+    """BASELINE.json's headline size (B=256, 32^3; bf16, and the fp8 MFMA mode): size-independent properties instead of a full oracle run --
     (1) any sample computed inside the 256-batch equals the same sample computed in a batch of 5 (tiles, split-K and
     position-major row order all change with B); (2) permuting the batch permutes the outputs; (3) IoU against the C
     oracle on a 16-sample subset within 1e-3."""
@@ -136,21 +137,21 @@ def test_full_batch_256_properties_bf16():
     ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
     x = syn.make_voxels(256, 32, seed=256)
     eps = syn.make_eps(256, 64, seed=257)
-    big = _run(cfg, ep, dp, x, x, eps, 'bf16')
+    big = _run(cfg, ep, dp, x, x, eps, dtname)
     pick = [0, 37, 128, 200, 255]
-    small = _run(cfg, ep, dp, x[pick], x[pick], eps[pick], 'bf16')
+    small = _run(cfg, ep, dp, x[pick], x[pick], eps[pick], dtname)
     d = np.abs(big['logits'][pick] - small['logits']).max()
-    assert d < 0.02 * np.abs(big['logits']).max(), d            # bf16 path, different accumulation splits
-    assert np.abs(big['stats'][pick, 1:] - small['stats'][:, 1:]).max() <= 0.002 * 32768
+    assert d < (0.02 if dtname == 'bf16' else 0.08) * np.abs(big['logits']).max(), d            # different accumulation splits; fp8 activations re-round
+    assert np.abs(big['stats'][pick, 1:] - small['stats'][:, 1:]).max() <= (0.002 if dtname == 'bf16' else 0.01) * 32768
     perm = np.random.default_rng(0).permutation(256)
-    pb = _run(cfg, ep, dp, x[perm], x[perm], eps[perm], 'bf16')
+    pb = _run(cfg, ep, dp, x[perm], x[perm], eps[perm], dtname)
     np.testing.assert_array_equal(pb['stats'], big['stats'][perm])          # same tiles, same order of operations per sample
     sub = list(range(0, 256, 16))
     c = co.vae_eval_forward(cfg, ep, dp, x[sub], x[sub], eps[sub])
     s = big['stats'][sub].astype(np.float64)
     iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3]).mean()
     iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64)).mean()
-    print('\n[B256 bf16] IoU gpu %.6f cpu %.6f' % (iou_g, iou_c))
+    print('\n[B256 %s] IoU gpu %.6f cpu %.6f' % (dtname, iou_g, iou_c))
     assert abs(iou_g - iou_c) <= 1e-3
 
 
