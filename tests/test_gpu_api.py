@@ -96,6 +96,14 @@ def test_fp8_inference_mode_api():
     assert m8._dec_eng.packed.get('q1') and m8._dec_eng.packed.get('q2')
     with pytest.raises(ValueError):
         m8.fit((x, x))
+    # the AE class (encoder output = latent, no sampling) and the 64^3 / latent-16 geometry run the same fp8 layers
+    for name in ('ae_d32_l64_b2', 'vae_d64_l16_b1'):
+        g2, _, m2, d2 = _model(name, 'fp8')
+        out2 = m2.getEval(inputs=(d2['x'], d2['x'], d2['oh']), category_vectors=d2['cats'], missing_prob=0.5, _eps=d2['eps'], _mask=d2['mask'],
+                          _eps2=d2['eps2'])
+        sc2 = np.array([float(v) for v in out2[1:5]] + [float(v) for v in out2[6:10]])
+        np.testing.assert_allclose(sc2[[0, 4]], g2['p5_scalars'][[0, 4]], rtol=0.03, err_msg=name)
+        np.testing.assert_allclose(sc2[[1, 2, 5, 6]], g2['p5_scalars'][[1, 2, 5, 6]], atol=0.03, err_msg=name)
 
 
 def test_builders_and_checkpoints(tmp_path):
