@@ -196,3 +196,18 @@ def test_fp8_weight_quantisation_host_side():
     wt = w.permute(0, 1, 2, 4, 3).contiguous()                                        # transposed-conv layout: cout at axis 3
     wq2, s2 = E.quant_fp8(wt, 3)
     assert torch.equal(s2, s) and torch.equal(wq2, wq.permute(0, 1, 2, 4, 3))
+
+
+def test_default_dtype_switch_accepts_the_three_modes():
+    import voxvae
+    keep = voxvae.default_dtype()
+    try:
+        for name in ('f32', 'bf16', 'fp8'):
+            voxvae.set_default_dtype(name)
+            assert voxvae.default_dtype() == name
+        with pytest.raises(ValueError):
+            voxvae.set_default_dtype('fp16')
+    finally:
+        voxvae.set_default_dtype(keep)
+    from voxvae import lib as L
+    assert (L.DTYPES['f32'], L.DTYPES['bf16'], L.DTYPES['fp8']) == (L.VV_F32, L.VV_BF16, L.VV_FP8) == (0, 1, 2)   # include/voxvae.h vv_dtype
