@@ -117,3 +117,7 @@ bool vv_wgrad_phase_ok(const void *src, const void *g, int batch, int side, int 
 size_t vv_wgrad_phase_ws(long rows, int cin, int cout);
 void vv_wgrad_phase_launch(const void *src, const void *g, float *slabs, int batch, int side, int cin, int cout, int *splits,
                            hipStream_t st);
+
+// final_bce_fp8.hip (internal): sweep-form last layer with an e4m3fn input; returns the partial blocks per sample.
+int vv_final_bce_sweep_fp8_launch(const void *x, const float *w_keras, const float *target, float *probs, float *logits, float *partials,
+                                  int batch, int side, float gamma, float epsilon, hipStream_t st);

@@ -44,10 +44,10 @@ __global__ void pack_convT_frag_fp8_kernel(const float *__restrict__ w, unsigned
     }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool OUT8>     // OUT8: store e4m3fn (for the fp8 last layer) instead of bf16
 __global__ __launch_bounds__(F8_NW * 64, 1) void convT_direct_fp8_kernel(const unsigned char *__restrict__ x, const uint4 *__restrict__ wf,
                                                                           const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                          __bf16 *__restrict__ y, int din_log2, unsigned x_bytes, int act) {
+                                                                          void *__restrict__ y, int din_log2, unsigned x_bytes, int act) {
     constexpr int MT = F8_MT, NW = F8_NW;
     constexpr int RB = CIN;              // bytes per voxel row
     constexpr int KS = CIN / 64;         // K = 64 MFMA steps per tap
@@ -205,27 +205,35 @@ __global__ __launch_bounds__(F8_NW * 64, 1) void convT_direct_fp8_kernel(const u
                 for (int g = 0; g < 4; ++g) {
                     const int c = nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = scv[nt][g], sh = shv[nt][g];
-                    bf16x4 o;
+                    f32x4 tv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = acc[mt][nt][4 * g + e] * sc[e] + sh[e];
                         if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
                         else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
                         else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                        o[e] = static_cast<__bf16>(t);
+                        tv[e] = t;
                     }
-                    *reinterpret_cast<bf16x4 *>(mystage + fr * SPITCH + c * 2) = o;
+                    if constexpr (OUT8) {
+                        *reinterpret_cast<unsigned *>(mystage + fr * SPITCH + c) = vv_pack_fp8x4(tv);
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(tv[e]);
+                        *reinterpret_cast<bf16x4 *>(mystage + fr * SPITCH + c * 2) = o;
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            constexpr int CPR = COUT * 2 / 16;            // 16-byte chunks per output row
+            constexpr int ES = OUT8 ? 1 : 2;
+            constexpr int CPR = COUT * ES / 16;           // 16-byte chunks per output row
 #pragma unroll
             for (int i = 0; i < 32 * CPR / 64; ++i) {
                 const int id = lane + 64 * i, r = id / CPR, c = id % CPR;
                 const int od = 2 * (d0 + mt) + pd, oh = 2 * (h0 + (r >> 3)) + ph, ow = 2 * (w0 + (r & 7)) + pw;
                 const size_t vox = (((((size_t)b << lo) + od) << lo) + oh << lo) + ow;
-                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (COUT * 2) + c * 16) =
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (COUT * ES) + c * 16) =
                     *reinterpret_cast<const uint4 *>(mystage + r * SPITCH + c * 16);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -261,8 +269,9 @@ VV_EXPORT int vv_pack_convT_k4s2_frag_fp8(const float *w_keras, void *packed, in
 }
 
 VV_EXPORT int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
-                                             int batch, int side, int cin, int cout, int act, void *stream) {
+                                             int batch, int side, int cin, int cout, int act, int out_dtype, void *stream) {
     if (!x || !w_frag || !y) return VV_ERR_NULL;
+    if (out_dtype != VV_BF16 && out_dtype != VV_FP8) return VV_ERR_DTYPE;
     if (!vv_convT3d_k4s2_direct_fp8_supported(side, cin, cout) || batch <= 0) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w_frag) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     const size_t xb = (size_t)batch * side * side * side * cin;
@@ -270,12 +279,17 @@ VV_EXPORT int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, 
     const int boxes = (side / F8_MT) * (side / 4) * (side / 8);
     constexpr int LDS = (F8_MT + 2) * HH * HW * 128 + F8_NW * 32 * (64 * 2 + 16);
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_fp8_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_fp8_kernel<128, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&convT_direct_fp8_kernel<128, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         return true;
     }();
     (void)attr;
-    VV_LAUNCH((convT_direct_fp8_kernel<128, 64>), dim3(batch * boxes), dim3(F8_NW * 64), LDS, reinterpret_cast<hipStream_t>(stream),
-              reinterpret_cast<const unsigned char *>(x), reinterpret_cast<const uint4 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y),
-              vv_log2(side), (unsigned)xb, act);
+    const unsigned char *xb8 = reinterpret_cast<const unsigned char *>(x);
+    const uint4 *wf4 = reinterpret_cast<const uint4 *>(w_frag);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (out_dtype == VV_FP8)
+        VV_LAUNCH((convT_direct_fp8_kernel<128, 64, true>), dim3(batch * boxes), dim3(F8_NW * 64), LDS, st, xb8, wf4, scale, shift, y, vv_log2(side), (unsigned)xb, act);
+    else
+        VV_LAUNCH((convT_direct_fp8_kernel<128, 64, false>), dim3(batch * boxes), dim3(F8_NW * 64), LDS, st, xb8, wf4, scale, shift, y, vv_log2(side), (unsigned)xb, act);
     return vv_launch_status();
 }

@@ -708,8 +708,9 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
                                        float *logits, float *stats, int batch, int side, int cin, float gamma,
                                        float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !w_keras || !target || !stats) return VV_ERR_NULL;
-    if (dtype != VV_F32 && dtype != VV_BF16) return VV_ERR_DTYPE;
+    if (dtype != VV_F32 && dtype != VV_BF16 && dtype != VV_FP8) return VV_ERR_DTYPE;
     if (batch <= 0 || batch > 65535 || side < 4 || !vv_is_pow2(side) || cin != FB_CIN) return VV_ERR_SHAPE;
+    if (dtype == VV_FP8 && side < 8) return VV_ERR_SHAPE;                  // the e4m3fn input exists in sweep form only
     if (!vv_aligned16(x) || !vv_aligned16(target) || (probs && !vv_aligned16(probs)) || (logits && !vv_aligned16(logits)))
         return VV_ERR_ALIGN;
     if (!workspace || workspace_bytes < vv_convT3d_final_bce_workspace_bytes(batch, side) || !vv_aligned16(workspace))
@@ -718,6 +719,11 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *partials = reinterpret_cast<float *>(workspace);
     const int ntile = (side / 8) * (side / 8);
+    if (dtype == VV_FP8) {
+        const int nt8 = vv_final_bce_sweep_fp8_launch(x, w_keras, target, probs, logits, partials, batch, side, gamma, epsilon, st);
+        VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nt8);
+        return vv_launch_status();
+    }
     const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "box": override the batch heuristic (tests)
     const bool sweep = dtype == VV_BF16 && side >= 8 &&
                        (force ? force[0] == 's' : (long)batch * ntile >= 128);   // enough workgroups to fill the chip

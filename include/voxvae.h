@@ -130,11 +130,12 @@ int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, const float *s
                                int batch, int side, int cin, int cout, int act, int dtype, void *stream);
 /* fp8 twin of the direct transposed layer (convt_direct_fp8.hip): x and w_frag in OCP e4m3fn (w_frag from
  * vv_pack_convT_k4s2_frag_fp8, which converts a float32 Keras kernel already divided by its per-output-channel scale; the
- * scale belongs in `scale`), block-scaled K = 64 MFMA, y stored as bf16.  Cin 128 -> Cout 64, side >= 8. */
+ * scale belongs in `scale`), block-scaled K = 64 MFMA, y stored as VV_BF16 or VV_FP8 (out_dtype; VV_FP8 feeds the fp8 form of
+ * vv_convT3d_final_bce_fwd).  Cin 128 -> Cout 64, side >= 8. */
 int vv_convT3d_k4s2_direct_fp8_supported(int side, int cin, int cout);
 int vv_pack_convT_k4s2_frag_fp8(const float *w_keras, void *packed, int cin, int cout, void *stream);
 int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
-                                   int batch, int side, int cin, int cout, int act, void *stream);
+                                   int batch, int side, int cin, int cout, int act, int out_dtype, void *stream);
 
 /* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
  * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).
@@ -160,6 +161,8 @@ int vv_reparam_kl_fwd(const float *enc_out, const float *eps, const float *drop_
  * (gamma, epsilon clip) and voxelPrecisionRecall at p >= 0.5 (autoencoder3D.py:129-136; function.py:73-82,
  * 100-115; nolbo.py:1496-1499).  x [B,D,D,D,Cin] dtype; w_keras [4,4,4,1,Cin] float32; target [B,2D,2D,2D]
  * float32; probs/logits [B,2D,2D,2D] float32 (either may be NULL); stats [B,4] = per-sample (bce,TP,FP,FN). */
+/* dtype VV_FP8: x in OCP e4m3fn (side >= 8; the kernel quantises w_keras per tap itself); probabilities, logits and the sums
+ * stay float32. */
 size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side);
 int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *target, float *probs, float *logits,
                              float *stats, int batch, int side, int cin, float gamma, float epsilon, int dtype,

@@ -549,7 +549,8 @@ def test_dense_and_convert_fp8(L):
     L.call('vv_pack_dense', L.ptr(_dev(w)), L.ptr(wp), k, n, L.VV_FP8, _st())
     y = torch.zeros(m, n, dtype=torch.float32, device=DEV)
     ws = torch.empty(max(L.load().vv_dense_workspace_bytes(m, n, k, L.VV_FP8), 16), dtype=torch.uint8, device=DEV)
-    L.call('vv_dense_fwd', L.ptr(_dev(x).to(F8)), L.ptr(wp), L.ptr(_dev(scale)), None, L.ptr(y), m, n, k, 0, L.VV_FP8, L.VV_F32, L.ptr(ws),
+    x8, scd = _dev(x).to(F8), _dev(scale)                   # named: raw pointers must outlive the launch
+    L.call('vv_dense_fwd', L.ptr(x8), L.ptr(wp), L.ptr(scd), None, L.ptr(y), m, n, k, 0, L.VV_FP8, L.VV_F32, L.ptr(ws),
            ws.numel(), _st())
     torch.cuda.synchronize()
     _check(y, ref, 'f32', 'dense fp8->f32')
@@ -560,7 +561,8 @@ def test_dense_and_convert_fp8(L):
     L.call('vv_pack_dense', L.ptr(_dev(wb)), L.ptr(wpb), 256, n, L.VV_BF16, _st())
     y8 = torch.zeros(m, n, dtype=F8, device=DEV)
     ws = torch.empty(max(L.load().vv_dense_workspace_bytes(m, n, 256, L.VV_BF16), 16), dtype=torch.uint8, device=DEV)
-    L.call('vv_dense_fwd', L.ptr(_dev(xb, torch.bfloat16)), L.ptr(wpb), None, None, L.ptr(y8), m, n, 256, 0, L.VV_BF16, L.VV_FP8, L.ptr(ws),
+    xbd = _dev(xb, torch.bfloat16)
+    L.call('vv_dense_fwd', L.ptr(xbd), L.ptr(wpb), None, None, L.ptr(y8), m, n, 256, 0, L.VV_BF16, L.VV_FP8, L.ptr(ws),
            ws.numel(), _st())
     torch.cuda.synchronize()
     _check_fp8_out(y8, ref2, 'dense bf16->fp8')
@@ -636,7 +638,11 @@ def test_convT3d_direct_fp8(L, B, side, act):
     wf = torch.empty(64 * cin * cout, dtype=torch.uint8, device=DEV)
     L.call('vv_pack_convT_k4s2_frag_fp8', L.ptr(wd), L.ptr(wf), cin, cout, _st())
     y = torch.full((B, 2 * side, 2 * side, 2 * side, cout), -7.0, dtype=torch.bfloat16, device=DEV)
-    L.call('vv_convT3d_k4s2_direct_fp8_fwd', L.ptr(xd), L.ptr(wf), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, act, _st())
+    L.call('vv_convT3d_k4s2_direct_fp8_fwd', L.ptr(xd), L.ptr(wf), L.ptr(sd), L.ptr(hd), L.ptr(y), B, side, cin, cout, act, L.VV_BF16, _st())
+    y8 = torch.zeros(B, 2 * side, 2 * side, 2 * side, cout, dtype=F8, device=DEV)
+    L.call('vv_convT3d_k4s2_direct_fp8_fwd', L.ptr(xd), L.ptr(wf), L.ptr(sd), L.ptr(hd), L.ptr(y8), B, side, cin, cout, act, L.VV_FP8, _st())
+    torch.cuda.synchronize()
+    _check_fp8_out(y8, ref, 'convT3d_direct_fp8 -> fp8')
     torch.cuda.synchronize()
     _check(y, ref, 'bf16', 'convT3d_direct_fp8')
     wp = torch.empty(8, cout, 8 * cin, dtype=F8, device=DEV)
@@ -684,3 +690,40 @@ def test_conv3d_direct_fp8(L, B, side, act, odt):
     torch.cuda.synchronize()
     d = (y.float() - y2.float()).abs().max().item()
     assert d <= 0.07 * max(1.0, float(np.abs(ref).max())), 'direct vs implicit GEMM (fp8): %.3e' % d
+
+
+@pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
+@pytest.mark.parametrize('B,side', [(2, 16), (3, 8), (1, 32)])
+def test_convT3d_final_bce_fp8_input(L, B, side):
+    """Last layer (sweep form) with an e4m3fn activation: the kernel quantises the float32 Keras kernel per tap itself, so the
+    float64 reference uses the same per-tap quantised weights; logits, probabilities, loss and TP/FP/FN as in the bf16 test."""
+    rng = np.random.default_rng(side + B)
+    x = _fp8_round(rng.standard_normal((B, side, side, side, 64)))
+    w = (rng.standard_normal((4, 4, 4, 1, 64)) * 0.3 * np.exp(rng.uniform(-2, 2, (4, 4, 4, 1, 1)))).astype(np.float32)   # taps of different magnitude
+    s_tap = (np.abs(w).max(axis=-1, keepdims=True) / np.float32(256.0)).astype(np.float32)
+    wq = _fp8_round((w * (np.float32(1.0) / s_tap)).astype(np.float32)).astype(np.float64) * s_tap       # the kernel's arithmetic: w * (1 / s)
+    D = 2 * side
+    y = (rng.random((B, D, D, D, 1)) < 0.3).astype(np.float32)
+    lg = no.conv3d_transpose_same(x.astype(np.float64), wq, 2)
+    pr = no.sigmoid(lg)
+    tp, fp, fn = no.voxel_precision_recall(y, pr.astype(np.float32))
+    ws = torch.empty(max(L.load().vv_convT3d_final_bce_workspace_bytes(B, side), 16), dtype=torch.uint8, device=DEV)
+    probs = torch.empty(B, D, D, D, 1, dtype=torch.float32, device=DEV)
+    logits = torch.empty_like(probs)
+    stats = torch.empty(B, 4, dtype=torch.float32, device=DEV)
+    xd, wd, yd = _dev(x).to(F8), _dev(w), _dev(y)            # named: the raw pointers must outlive the launch
+    L.call('vv_convT3d_final_bce_fwd', L.ptr(xd), L.ptr(wd), L.ptr(yd), L.ptr(probs), L.ptr(logits), L.ptr(stats), B, side, 64,
+           0.6, 1e-7, L.VV_FP8, L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    glg = logits.cpu().numpy().astype(np.float64)
+    assert np.abs(glg - lg).max() < 3e-5 * max(1.0, np.abs(lg).max())         # exact fp8 x fp8 products, float32 accumulation
+    np.testing.assert_allclose(probs.cpu().numpy(), pr, rtol=0, atol=0.25 * 3e-5 * max(1.0, np.abs(lg).max()) + 1e-6)   # dp <= 0.25 * dlogit
+    s = stats.cpu().numpy().astype(np.float64)
+    bce = no.binary_loss(pr.astype(np.float32), y, gamma=0.6)
+    np.testing.assert_allclose(s[:, 0], bce, rtol=2e-3)
+    flips = int(((glg >= 0) != (lg >= 0)).sum())
+    assert flips == 0 or np.abs(lg[(glg >= 0) != (lg >= 0)]).max() < 1e-5
+    for k, r in ((1, tp), (2, fp), (3, fn)):
+        assert np.abs(s[:, k] - r).max() <= flips
+    assert L.load().vv_convT3d_final_bce_fwd(L.ptr(xd), L.ptr(wd), L.ptr(yd), L.ptr(probs), L.ptr(logits), L.ptr(stats), B, 4, 64,
+                                             0.6, 1e-7, L.VV_FP8, L.ptr(ws), ws.numel(), _st()) == -2
