@@ -155,12 +155,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || MT == 4) ? 1 : 2) void convT_d
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&bfk[nt]),
                                                                           *reinterpret_cast<const bf16x8 *>(&F[mt]), acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(acc[mt][0]), "+v"(acc[mt][NT - 1]));   // pin the MFMAs here (they are pure)
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);     // (pinning the MFMAs with an asm on the accumulators, as the fp8 twin does, is neutral
+                                                   // for the 8-wave form and 2.5x slower for the 4-wave MT = 4 form: not used here)
         };
         // one group = HALF k-steps of one tap with the weights of ring buffer bf; k-steps alternate P, Q (HALF is even)
-        constexpr bool PINGPONG = !(MT == 4 && NW == 8);    // the 8-wave form has no registers left for a second set (tried again with pinned MFMAs: 300 B of spills)
+        constexpr bool PINGPONG = !(MT == 4 && NW == 8);    // the 8-wave form has no registers left for a second set (300 B of spills when forced)
         static_assert(!PINGPONG || HALF % 2 == 0, "P/Q roles must line up across groups");
         auto compute_group = [&](int g, const uint4 *bf) {
             const int a = g / GPT, part = g % GPT;
