@@ -1,0 +1,513 @@
+// Stride-2 convolution / transposed convolution on a 4^3 cell grid with whole samples resident in LDS and the taps that
+// fall into the SAME padding skipped at MFMA granularity (bf16, gfx950).
+//
+//   conv  : Conv3D          k4 s2 SAME,  8^3 x Cin -> 4^3 x Cout   (autoencoder3D.py:26-39;  32^3 model: 128 -> 256)
+//   convT : Conv3DTranspose k4 s2 SAME,  4^3 x Cin -> 8^3 x Cout   (autoencoder3D.py:41-54;  32^3 model: 256 -> 128)
+//
+// Both have 64 "cells" per sample (conv: the 4^3 outputs, convT: the 4^3 inputs) and a batch of samples.  The implicit
+// GEMM runs them position-major (rows = samples at one position) so that padded taps can be dropped, but then no input row
+// is ever reused inside a workgroup: every (row, tap) is a fresh 128-byte segment through L2 -> LDS, and the kernel sits on
+// its per-chunk DMA latency (rocprofv3: 20-23 % MFMA busy, 44-54 % of wave cycles parked on s_waitcnt / s_barrier).
+// Here a workgroup owns 4 whole samples:
+//
+//   rows      : MFMA row tile = 16 rows = (4 w positions) x (4 samples) at ONE (d, h) -> a tap is valid or padding for the
+//               whole tile in d and h, so v_mfma_f32_16x16x32_bf16 tiles are skipped exactly where the d / h index leaves the
+//               grid (23 % of the dense work); along w the out-of-grid lanes read a zero row instead.
+//   A tile    : conv: the phase sub-grid X_q[j] = x[2j + 1 - q] (j = 0..3 per axis, all real data: 8 phases x Cin/64 chunks);
+//               convT: the input cells themselves (Cin/64 chunks).  [4 samples][4][4][4] rows of 128 B = 32 KiB, double
+//               buffered, staged once by LDS-DMA: every input byte crosses L2 -> LDS once per workgroup, not once per tap.
+//   weights   : [tap][Cin/64][Cout][64] (conv) / [parity][tap][Cin/64][Cout][64] (convT) panels, a 32 KiB stage per unit
+//               (conv: 4 taps x 64 channels; convT: 1 tap x 2 parities x 128 channels) in a 2-deep ring, LDS-DMA, fully
+//               coalesced 8 / 16 KiB pieces.
+//   waves     : 8 = 4 row groups x 2; a row group holds the 4 row tiles (d, (d + g) & 3), d = 0..3, so every wave skips the
+//               same share of tiles.  conv: the two waves of a row group split K (k-step 0 / 1 of each 64-channel chunk, 64
+//               channels, summed through LDS at the end); convT: they take the two w parities (128 channels each).
+//   sync      : one barrier per unit (= 2048 matrix-pipe cycles per SIMD): vmcnt(0) + barrier publishes the stage that flew
+//               during the previous unit; fragment reads are inline asm one step ahead of their MFMAs with counted lgkmcnt.
+//   workgroups: (batch / 4) x (Cout / 64) for conv, (batch / 4) x 4 parity pairs x (Cout / 128) for convT; ordered so that
+//               the groups of one sample quad run on one XCD.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned sd_u4;
+
+constexpr int SD_ATILE = 256 * 128;        // [4 s][4][4][4] rows x 128 B
+constexpr int SD_WST = 32768;              // one weight stage
+constexpr int SD_W0 = 2 * SD_ATILE;        // weight ring behind the two A buffers
+constexpr int SD_ZERO = SD_W0 + 2 * SD_WST;   // 256 B of zeros: the row every out-of-grid w lane reads
+constexpr int SD_LDS = SD_ZERO + 256;      // 131,328 B
+constexpr int SD_XCH = 0;                  // conv epilogue: K-half exchange [8 waves][8][64 lanes] f32x4 = 64 KiB
+constexpr int SD_OST = 65536;              // conv epilogue: [256 rows][144 B] output staging
+constexpr int SD_OPITCH = 144;
+constexpr int SD_TPITCH = 272;             // convT epilogue: per-wave [16 rows][256 B + 16]
+constexpr int SD_TWAVE = 16 * SD_TPITCH;
+
+struct SdArgs {
+    const void *x;
+    const void *w;
+    const float *scale;
+    const float *shift;
+    void *y;
+    int batch, cin, cout, act;
+    unsigned x_bytes, w_bytes;
+    int groups;                            // workgroups per sample quad
+};
+
+// out[((t*NC + c)*cout + n)*64 + k] = w[(t*cin + c*64 + k)*cout + n]          (Keras Conv3D [kd,kh,kw,Cin,Cout])
+__global__ void sd_pack_conv_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    const int NC = cin / 64;
+    const long total = (long)64 * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 63);
+        long r = i >> 6;
+        const int n = (int)(r % cout); r /= cout;
+        const int c = (int)(r % NC);
+        const int t = (int)(r / NC);
+        out[i] = static_cast<__bf16>(w[((size_t)t * cin + c * 64 + k) * cout + n]);
+    }
+}
+
+// out[((((p*8 + a)*NC + c)*cout + n)*64 + k] = w[(t(p,a)*cout + n)*cin + c*64 + k],  t = 1 - p + 2a per axis
+// (Keras Conv3DTranspose [kd,kh,kw,Cout,Cin])
+__global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    const int NC = cin / 64;
+    const long total = (long)64 * cin * cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 63);
+        long r = i >> 6;
+        const int n = (int)(r % cout); r /= cout;
+        const int c = (int)(r % NC); r /= NC;
+        const int a = (int)(r & 7), p = (int)(r >> 3);
+        const int td = 1 - ((p >> 2) & 1) + 2 * ((a >> 2) & 1);
+        const int th = 1 - ((p >> 1) & 1) + 2 * ((a >> 1) & 1);
+        const int tw = 1 - (p & 1) + 2 * (a & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        out[i] = static_cast<__bf16>(w[((size_t)t * cout + n) * cin + c * 64 + k]);
+    }
+}
+
+#define SD_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+// LDS returns in order: lgkmcnt(N) = everything but the N youngest reads has landed.  Naming the fragments as "+v" ties the
+// MFMAs that consume them below this statement.
+#define SD_WAIT8(N, F, G)                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                    \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3])          \
+                 : "n"(N)                                                                                                   \
+                 : "memory")
+
+// MODE 0 = conv (8^3 -> 4^3), MODE 1 = convT (4^3 -> 8^3)
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mq = wave & 3, hv = wave >> 2;          // row group; conv: K half (k-step), convT: w parity
+    const int NC = a.cin >> 6;
+
+    // XCD-aware order: the `groups` workgroups of a sample quad, then the next quads, walk one XCD
+    const int nwg = gridDim.x;
+    const int wi = (nwg & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+    const int sg = wi / a.groups, g = wi - sg * a.groups;
+    const int b0 = sg * 4;
+    // conv: g = channel group of 64; convT: g = parity pair (pd, ph) + 4 * channel group of 128
+    const int ng = MODE == 0 ? g : (g >> 2);
+    const int pd = (g >> 1) & 1, ph = g & 1;          // convT only
+
+    const u32x4 rsx = vv_make_rsrc(a.x, a.x_bytes), rsw = vv_make_rsrc(a.w, a.w_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    if (tid < 16) reinterpret_cast<uint4 *>(smem + SD_ZERO)[tid] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // ---- producers.  A tile row R = ((s*4 + jd)*4 + jh)*4 + jw, slot swizzle f(R) = ((s & 1) << 2) | (jw & 2): with
+    // R & 1 = jw & 1 the 16 lanes of every ds_read_b128 lane group (rows {0-3,12-15} of k-quarter kq, rows {4-11} of kq ^ 1)
+    // land on 16 different 16-byte bank positions.  The swizzle is applied to the SOURCE slot; LDS is written linearly.
+    auto issue_a = [&](int T, int k) {            // piece k (0..3) of this wave for tile T into buffer T & 1
+        const int it = wave * 4 + k;
+        const int R = it * 8 + (lane >> 3);
+        const int s = R >> 6, jd = (R >> 4) & 3, jh = (R >> 2) & 3, jw = R & 3;
+        const int f = ((s & 1) << 2) | (jw & 2);
+        const int slot = (lane & 7) ^ f;
+        unsigned vo;
+        if (MODE == 0) {
+            const int q = T / NC, c = T - q * NC;
+            const int xd = 2 * jd + 1 - ((q >> 2) & 1), xh = 2 * jh + 1 - ((q >> 1) & 1), xw = 2 * jw + 1 - (q & 1);
+            vo = (unsigned)(((((b0 + s) * 8 + xd) * 8 + xh) * 8 + xw) * (a.cin * 2) + c * 128 + slot * 16);
+        } else {
+            vo = (unsigned)((((b0 + s) * 64) + (R & 63)) * (a.cin * 2) + T * 128 + slot * 16);
+        }
+        vv_dma16(rsx, vo, lds0 + (T & 1) * SD_ATILE + it * 1024);
+    };
+    // weight rows n of a stage: slot swizzle (n >> 1) & 7 (the implicit GEMM's, conflict-free for consecutive rows)
+    auto issue_w = [&](int u) {                   // the 4 pieces of this wave for unit u into ring[u & 1]
+        const unsigned st = lds0 + SD_W0 + (u & 1) * SD_WST;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int it = wave * 4 + k;
+            unsigned src, nrow;
+            if (MODE == 0) {
+                const int T = u >> 1, ad = u & 1;
+                const int q = T / NC, c = T - q * NC;
+                const int j = it >> 3, blk = it & 7;                       // tap j of the unit, 8-row block
+                const int td = 2 * ad + ((q >> 2) & 1), th = 2 * (j >> 1) + ((q >> 1) & 1), tw = 2 * (j & 1) + (q & 1);
+                const int t = (td * 4 + th) * 4 + tw;
+                nrow = blk * 8 + (lane >> 3);
+                src = (unsigned)(((t * NC + c) * a.cout + ng * 64) * 128);
+            } else {
+                const int c = u >> 3, ta = u & 7;
+                const int pi = it >> 4, blk = it & 15;
+                const int p = pd * 4 + ph * 2 + pi;
+                nrow = blk * 8 + (lane >> 3);
+                src = (unsigned)((((p * 8 + ta) * NC + c) * a.cout + ng * 128) * 128);
+            }
+            const unsigned slot = (lane & 7) ^ ((nrow >> 1) & 7);
+            vv_dma16(rsw, src + nrow * 128 + slot * 16, st + it * 1024);
+        }
+    };
+
+    // ---- consumer addressing
+    const int r = lane & 15, kq = lane >> 4, ls = r >> 2, lw = r & 3;
+    auto arow = [&](int jw, int ks) -> unsigned {       // (s, jd = 0, jh = 0, jw), k-step ks: byte offset inside an A tile
+        const int f = ((ls & 1) << 2) | (jw & 2);
+        return (unsigned)((ls * 64 + jw) * 128 + ((((ks << 2) | kq) ^ f) << 4));
+    };
+    const unsigned zaddr = lds0 + SD_ZERO + kq * 16;
+    // weight fragment: row n = lane & 15 of a 16-channel tile, k-quarter kq
+    unsigned wb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wb[ks] = lds0 + SD_W0 + (unsigned)(r * 128 + ((((ks << 2) | kq) ^ ((r >> 1) & 7)) << 4));
+
+    // row tiles of this wave: (d, h) = (i, (i + mq) & 3)
+    int td_[4], th_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { td_[i] = i; th_[i] = (i + mq) & 3; }
+
+    constexpr int NT = MODE == 0 ? 4 : 8;               // 16-channel tiles per wave
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // One step: 4 x fragments (row tiles) + 4 weight fragments (channel tiles nt0..nt0+3) -> up to 16 MFMAs.
+    // dd, dh = the tap's cell offset in d / h (-1, 0, +1); tiles whose d / h index leaves 0..3 are skipped (their fragment is
+    // still read, from the tile's own cell, so that the lgkmcnt counts stay static).  The w offset is folded into `base`
+    // (a per-lane byte offset prepared per tap variant); lanes whose w index leaves the grid read the zero row.
+    auto x_addr = [&](int i, unsigned abuf, int dd, int dh, unsigned base, bool wok, int &vmask) -> unsigned {
+        const int jd = td_[i] + dd, jh = th_[i] + dh;
+        const bool valid = (unsigned)jd < 4u && (unsigned)jh < 4u;
+        vmask |= valid ? (1 << i) : 0;
+        const int od = valid ? jd : td_[i], oh = valid ? jh : th_[i];
+        const unsigned real = base + (abuf + (unsigned)(od * 2048 + oh * 512));
+        return wok ? real : zaddr;
+    };
+    auto mma16 = [&](const sd_u4 *xf, const sd_u4 *wf, int nt0, int vmask) {
+        vmask = __builtin_amdgcn_readfirstlane(vmask);   // wave-uniform by construction: keep the tile tests on the scalar unit
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (vmask & (1 << i)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[j]),
+                                                                               *reinterpret_cast<const bf16x8 *>(&xf[i]),
+                                                                               acc[i][nt0 + j], 0, 0, 0);
+            }
+        }
+    };
+
+    // convT: the w offset of a tap is hv - aw, fixed per wave: aw = 0 -> w + hv, aw = 1 -> w + hv - 1
+    const int tjw0 = lw + hv, tjw1 = lw + hv - 1;
+    const unsigned tb0[2] = {arow(tjw0 & 3, 0), arow(tjw0 & 3, 1)}, tb1[2] = {arow(tjw1 & 3, 0), arow(tjw1 & 3, 1)};
+    const bool tok0 = (unsigned)tjw0 < 4u, tok1 = (unsigned)tjw1 < 4u;
+
+    const int ntiles = MODE == 0 ? 8 * NC : NC;         // A tiles
+    const int upt = MODE == 0 ? 2 : 8;                  // units per A tile
+    const int nunits = ntiles * upt;
+
+    // ---- prologue
+#pragma unroll
+    for (int k = 0; k < 4; ++k) issue_a(0, k);
+    issue_w(0);
+
+#pragma unroll 1
+    for (int u = 0; u < nunits; ++u) {
+        const int T = MODE == 0 ? (u >> 1) : (u >> 3);
+        const int first = MODE == 0 ? ((u & 1) == 0) : ((u & 7) == 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (u + 1 < nunits) issue_w(u + 1);
+        if (first && T + 1 < ntiles) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) issue_a(T + 1, k);
+        }
+        const unsigned abuf = lds0 + (T & 1) * SD_ATILE;
+        const unsigned wst = (u & 1) * SD_WST;
+        sd_u4 xP[4], xQ[4], wP[4], wQ[4];
+        int vP = 0, vQ = 0;
+        if constexpr (MODE == 0) {
+            // unit = taps (ad = u & 1, ah, aw), this wave's k-step hv of the 64-channel chunk
+            const int q = T / NC;
+            const int qd = (q >> 2) & 1, qh = (q >> 1) & 1, qw = q & 1;
+            const int dd = (u & 1) - (1 - qd);
+            // per-lane bases of the two w variants of this phase: aw = 0 -> w - (1 - qw), aw = 1 -> w + qw
+            const int jw0 = lw - (1 - qw), jw1 = lw + qw;
+            const unsigned xb0 = arow(jw0 & 3, hv), xb1 = arow(jw1 & 3, hv);
+            const bool ok0 = (unsigned)jw0 < 4u, ok1 = (unsigned)jw1 < 4u;
+            const unsigned wsel0 = (hv ? wb[1] : wb[0]) + wst;
+            auto rd = [&](int j, sd_u4 *xf, sd_u4 *wf, int &vv) {
+                const int dh = (j >> 1) - (1 - qh);
+                vv = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned ad_ = x_addr(i, abuf, dd, dh, (j & 1) ? xb1 : xb0, (j & 1) ? ok1 : ok0, vv);
+                    SD_RD(xf[i], ad_, 0);
+                }
+                const unsigned wsel = wsel0 + (unsigned)(j * 8192);
+                SD_RD(wf[0], wsel, 0);
+                SD_RD(wf[1], wsel, 2048);
+                SD_RD(wf[2], wsel, 4096);
+                SD_RD(wf[3], wsel, 6144);
+            };
+            rd(0, xP, wP, vP);
+            rd(1, xQ, wQ, vQ);
+            SD_WAIT8(8, xP, wP);
+            mma16(xP, wP, 0, vP);
+            rd(2, xP, wP, vP);
+            SD_WAIT8(8, xQ, wQ);
+            mma16(xQ, wQ, 0, vQ);
+            rd(3, xQ, wQ, vQ);
+            SD_WAIT8(8, xP, wP);
+            mma16(xP, wP, 0, vP);
+            SD_WAIT8(0, xQ, wQ);
+            mma16(xQ, wQ, 0, vQ);
+        } else {
+            // unit = tap a = u & 7 of this wave's parity (pd, ph, hv): both k-steps x two channel halves
+            const int ta = u & 7;
+            const int dd = pd - ((ta >> 2) & 1), dh = ph - ((ta >> 1) & 1);
+            const unsigned wbase0 = wb[0] + wst + (unsigned)(hv * 16384), wbase1 = wb[1] + wst + (unsigned)(hv * 16384);
+            const bool aw = ta & 1;
+            auto rdx = [&](int ks, sd_u4 *xf, int &vv) {
+                vv = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned ad_ = x_addr(i, abuf, dd, dh, aw ? tb1[ks] : tb0[ks], aw ? tok1 : tok0, vv);
+                    SD_RD(xf[i], ad_, 0);
+                }
+            };
+            // weight fragments of channel tiles 0..3 / 4..7
+            rdx(0, xP, vP);
+            SD_RD(wP[0], wbase0, 0); SD_RD(wP[1], wbase0, 2048); SD_RD(wP[2], wbase0, 4096); SD_RD(wP[3], wbase0, 6144);
+            SD_RD(wQ[0], wbase0, 8192); SD_RD(wQ[1], wbase0, 10240); SD_RD(wQ[2], wbase0, 12288); SD_RD(wQ[3], wbase0, 14336);
+            SD_WAIT8(4, xP, wP);                    // x (k-step 0) and channel tiles 0..3 are in
+            mma16(xP, wP, 0, vP);
+            rdx(1, xQ, vQ);
+            SD_RD(wP[0], wbase1, 0); SD_RD(wP[1], wbase1, 2048); SD_RD(wP[2], wbase1, 4096); SD_RD(wP[3], wbase1, 6144);
+            SD_WAIT8(8, xP, wQ);                    // channel tiles 4..7 of k-step 0
+            mma16(xP, wQ, 4, vP);
+            SD_RD(wQ[0], wbase1, 8192); SD_RD(wQ[1], wbase1, 10240); SD_RD(wQ[2], wbase1, 12288); SD_RD(wQ[3], wbase1, 14336);
+            SD_WAIT8(4, xQ, wP);
+            mma16(xQ, wP, 0, vQ);
+            SD_WAIT8(0, xQ, wQ);
+            mma16(xQ, wQ, 4, vQ);
+        }
+    }
+    __builtin_amdgcn_s_barrier();                  // every fragment read has returned: the stages are free
+
+    const int kq4 = kq * 4;
+    if constexpr (MODE == 0) {
+        // ---- the two K halves of a row group exchange the channel tiles they do not finish: wave hv keeps tiles 2hv, 2hv+1
+        f32x4 *xch = reinterpret_cast<f32x4 *>(smem + SD_XCH);
+        {
+            f32x4 *mine = xch + (size_t)wave * 8 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mine[(i * 2 + j) * 64] = hv ? acc[i][j] : acc[i][2 + j];
+        }
+        __syncthreads();
+        f32x4 fin[4][2];
+        {
+            const f32x4 *theirs = xch + (size_t)(wave ^ 4) * 8 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fin[i][j] = (hv ? acc[i][2 + j] : acc[i][j]) + theirs[(i * 2 + j) * 64];
+        }
+        // folded BN + activation; lane = output row (sample ls, w lw) of tile (d, h), registers = 4 consecutive channels
+        f32x4 sc[2], sh[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = ng * 64 + (2 * hv + j) * 16 + kq4;
+            sc[j] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sh[j] = a.shift ? *reinterpret_cast<const f32x4 *>(a.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto fill = [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = ls * 64 + td_[i] * 16 + th_[i] * 4 + lw;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = fin[i][j][e] * sc[j][e] + sh[j][e];
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        o[e] = static_cast<__bf16>(t);
+                    }
+                    *reinterpret_cast<bf16x4 *>(smem + SD_OST + row * SD_OPITCH + ((2 * hv + j) * 16 + kq4) * 2) = o;
+                }
+            }
+        };
+        switch (a.act) {
+            case VV_ACT_ELU: fill(std::integral_constant<int, VV_ACT_ELU>{}); break;
+            case VV_ACT_RELU: fill(std::integral_constant<int, VV_ACT_RELU>{}); break;
+            case VV_ACT_LRELU: fill(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+            default: fill(std::integral_constant<int, VV_ACT_NONE>{}); break;
+        }
+        __syncthreads();
+        // 256 rows x 128 B leave as 16-byte pieces: 8 lanes per output row
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = tid + 512 * k, row = id >> 3, pc = id & 7;
+            const int b = b0 + (row >> 6);
+            if (b < a.batch)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.y) + ((size_t)b * 64 + (row & 63)) * (a.cout * 2) + ng * 128 + pc * 16) =
+                    *reinterpret_cast<const uint4 *>(smem + SD_OST + row * SD_OPITCH + pc * 16);
+        }
+    } else {
+        // ---- convT: lane = cell (sample ls, mw = lw) of tile (md, mh); output voxel (2 md + pd, 2 mh + ph, 2 mw + hv)
+        char *mystage = smem + wave * SD_TWAVE;
+        f32x4 sc[NT], sh[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = ng * 128 + j * 16 + kq4;
+            sc[j] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            sh[j] = a.shift ? *reinterpret_cast<const f32x4 *>(a.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto fill = [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[i][j][e] * sc[j][e] + sh[j][e];
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        o[e] = static_cast<__bf16>(t);
+                    }
+                    *reinterpret_cast<bf16x4 *>(mystage + r * SD_TPITCH + (j * 16 + kq4) * 2) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int od = 2 * td_[i] + pd, oh = 2 * th_[i] + ph;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int id = lane + 64 * k, row = id >> 4, pc = id & 15;
+                    const int b = b0 + (row >> 2), ow = 2 * (row & 3) + hv;
+                    if (b < a.batch)
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(a.y) + ((((size_t)b * 8 + od) * 8 + oh) * 8 + ow) * (a.cout * 2) + ng * 256 + pc * 16) =
+                            *reinterpret_cast<const uint4 *>(mystage + row * SD_TPITCH + pc * 16);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        switch (a.act) {
+            case VV_ACT_ELU: fill(std::integral_constant<int, VV_ACT_ELU>{}); break;
+            case VV_ACT_RELU: fill(std::integral_constant<int, VV_ACT_RELU>{}); break;
+            case VV_ACT_LRELU: fill(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+            default: fill(std::integral_constant<int, VV_ACT_NONE>{}); break;
+        }
+    }
+}
+
+inline int sd_grid_1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+template <int MODE>
+int sd_launch(const void *x, const void *w, const float *scale, const float *shift, void *y, int batch, int cin, int cout, int act,
+              hipStream_t st) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sd_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SD_LDS);
+        return true;
+    }();
+    (void)attr;
+    const size_t in_vox = MODE == 0 ? 512 : 64, out_vox = MODE == 0 ? 64 : 512;
+    const size_t sample_in = in_vox * cin * 2, sample_out = out_vox * cout * 2;
+    // 32-bit buffer offsets: a launch covers at most 2 GiB of input; larger batches go out as several launches (sample quads
+    // are independent)
+    int per = (int)((0x7FFFFFFFull / sample_in) & ~3ull);
+    if (per < 4) return VV_ERR_SHAPE;
+    for (int s0 = 0; s0 < batch; s0 += per) {
+        const int nb = batch - s0 < per ? batch - s0 : per;
+        SdArgs a;
+        a.x = reinterpret_cast<const char *>(x) + (size_t)s0 * sample_in;
+        a.y = reinterpret_cast<char *>(y) + (size_t)s0 * sample_out;
+        a.w = w; a.scale = scale; a.shift = shift;
+        a.batch = nb; a.cin = cin; a.cout = cout; a.act = act;
+        a.x_bytes = (unsigned)((size_t)nb * sample_in);
+        a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
+        a.groups = MODE == 0 ? cout / 64 : 4 * (cout / 128);
+        const int nsg = (nb + 3) / 4;
+        VV_LAUNCH(sd_kernel<MODE>, dim3(nsg * a.groups), dim3(512), SD_LDS, st, a);
+        const int rc = vv_launch_status();
+        if (rc != VV_OK) return rc;
+    }
+    return VV_OK;
+}
+
+}  // namespace
+
+VV_EXPORT int vv_conv3d_k4s2_skip_supported(int side, int cin, int cout, int dtype) {
+    return dtype == VV_BF16 && side == 8 && cin >= 64 && cin % 64 == 0 && cout >= 64 && cout % 64 == 0 && (size_t)64 * cin * cout * 2 < 0xFFFFFFF0ull;
+}
+
+VV_EXPORT int vv_convT3d_k4s2_skip_supported(int side, int cin, int cout, int dtype) {
+    return dtype == VV_BF16 && side == 4 && cin >= 64 && cin % 64 == 0 && cout >= 128 && cout % 128 == 0 && (size_t)64 * cin * cout * 2 < 0xFFFFFFF0ull;
+}
+
+VV_EXPORT int vv_pack_conv_k4_skip(const float *w_keras, void *packed, int cin, int cout, void *stream) {
+    if (!w_keras || !packed) return VV_ERR_NULL;
+    if (cin <= 0 || cout <= 0 || cin % 64) return VV_ERR_SHAPE;
+    VV_LAUNCH(sd_pack_conv_kernel, dim3(sd_grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+              reinterpret_cast<__bf16 *>(packed), cin, cout);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_pack_convT_k4s2_skip(const float *w_keras, void *packed, int cin, int cout, void *stream) {
+    if (!w_keras || !packed) return VV_ERR_NULL;
+    if (cin <= 0 || cout <= 0 || cin % 64) return VV_ERR_SHAPE;
+    VV_LAUNCH(sd_pack_convT_kernel, dim3(sd_grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+              reinterpret_cast<__bf16 *>(packed), cin, cout);
+    return vv_launch_status();
+}
+
+VV_EXPORT int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                                      int side, int cin, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_skip || !y) return VV_ERR_NULL;
+    if (!vv_conv3d_k4s2_skip_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_skip) || !vv_aligned16(y) || (scale && !vv_aligned16(scale)) || (shift && !vv_aligned16(shift)))
+        return VV_ERR_ALIGN;
+    return sd_launch<0>(x, w_skip, scale, shift, y, batch, cin, cout, act, reinterpret_cast<hipStream_t>(stream));
+}
+
+VV_EXPORT int vv_convT3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                                       int side, int cin, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_skip || !y) return VV_ERR_NULL;
+    if (!vv_convT3d_k4s2_skip_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_skip) || !vv_aligned16(y) || (scale && !vv_aligned16(scale)) || (shift && !vv_aligned16(shift)))
+        return VV_ERR_ALIGN;
+    return sd_launch<1>(x, w_skip, scale, shift, y, batch, cin, cout, act, reinterpret_cast<hipStream_t>(stream));
+}

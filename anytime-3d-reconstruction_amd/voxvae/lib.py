@@ -48,6 +48,12 @@ SIGNATURES = {
     'vv_convT3d_k4s2_direct_fp8_supported': (_i, [_i, _i, _i]),
     'vv_pack_convT_k4s2_frag_fp8': (_i, [_vp, _vp, _i, _i, _vp]),
     'vv_convT3d_k4s2_direct_fp8_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'vv_conv3d_k4s2_skip_supported': (_i, [_i, _i, _i, _i]),
+    'vv_convT3d_k4s2_skip_supported': (_i, [_i, _i, _i, _i]),
+    'vv_pack_conv_k4_skip': (_i, [_vp, _vp, _i, _i, _vp]),
+    'vv_pack_convT_k4s2_skip': (_i, [_vp, _vp, _i, _i, _vp]),
+    'vv_conv3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'vv_convT3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_dense_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'vv_dense_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_reparam_kl_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -137,6 +137,23 @@ int vv_pack_convT_k4s2_frag_fp8(const float *w_keras, void *packed, int cin, int
 int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, const float *scale, const float *shift, void *y,
                                    int batch, int side, int cin, int cout, int act, int out_dtype, void *stream);
 
+/* conv3DEnc / conv3DDec between the 8^3 and the 4^3 grid (autoencoder3D.py:26-54; the 32^3 model's 128 -> 256 and
+ * 256 -> 128 layers, the 64^3 model's 256 -> 512 and 512 -> 256) with four whole samples resident in LDS per workgroup
+ * and the taps that fall into the SAME padding skipped at MFMA-tile granularity in d and h (bf16 only).
+ *   conv : x [B,8,8,8,Cin] -> y [B,4,4,4,Cout], Cin % 64 == 0, Cout % 64 == 0; w_skip = vv_pack_conv_k4_skip
+ *          = [64 taps][Cin/64][Cout][64]
+ *   convT: x [B,4,4,4,Cin] -> y [B,8,8,8,Cout], Cin % 64 == 0, Cout % 128 == 0; w_skip = vv_pack_convT_k4s2_skip
+ *          = [8 parities][8 taps][Cin/64][Cout][64], tap t = 1 - p + 2a per axis
+ * No workspace; batches whose input passes 2 GiB go out as several launches. */
+int vv_conv3d_k4s2_skip_supported(int side, int cin, int cout, int dtype);
+int vv_convT3d_k4s2_skip_supported(int side, int cin, int cout, int dtype);
+int vv_pack_conv_k4_skip(const float *w_keras, void *packed, int cin, int cout, void *stream);
+int vv_pack_convT_k4s2_skip(const float *w_keras, void *packed, int cin, int cout, void *stream);
+int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                            int side, int cin, int cout, int act, int dtype, void *stream);
+int vv_convT3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                             int side, int cin, int cout, int act, int dtype, void *stream);
+
 /* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
  * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).
  * out_dtype may differ from dtype (the encoder output is float32). */

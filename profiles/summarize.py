@@ -7,6 +7,20 @@ unique per layer at a fixed batch.
 
   summarize.py bygrid  <kernel_trace.csv>                  -> CSV on stdout: kernel, grid, calls, avg/min/max ns
   summarize.py traffic <fetch_cc.csv> <write_cc.csv> LAYER=substr:grid ...   -> JSON on stdout
+  summarize.py counters <counter_collection.csv> [...]     -> CSV on stdout: one row per (kernel, grid) with the average of
+                                                              every counter in the given passes, the dispatch time, and the
+                                                              derived columns below
+  summarize.py stamp                                        -> JSON: git HEAD + sha256 over csrc/ and include/ (evidence stamp)
+
+Derived columns of `counters` (units: /opt/skills/guides/MI355X_MICROARCH.md, cycle-constants table -- SQ_BUSY_CYCLES and
+SQ_VALU_MFMA_BUSY_CYCLES count cycles, summed over the chip's SQs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+quad-cycles per wave):
+  mfma_busy_pct   = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES-equivalent) -- computed here as
+                    SQ_VALU_MFMA_BUSY_CYCLES / (kernel ns x 2.4 GHz x 256 CUs x 4 SIMDs)  (share of the chip's matrix-pipe
+                    cycles at the 2.4 GHz peak clock that carried an MFMA: directly comparable with the roofline fraction)
+  wait_lds_pct / wait_any_pct / wait_inst_pct / active_pct = that counter / SQ_WAVE_CYCLES
+  l2_hit_pct      = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)
+  fetch_MB        = 2 x FETCH_SIZE KiB (gfx950 correction), write_MB = WRITE_SIZE KiB
 
 `traffic` applies the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
 WRITE_SIZE are in KiB; FETCH_SIZE under-reports 16-B/lane streaming reads by 2x on gfx950 and is doubled;
@@ -61,8 +75,70 @@ def traffic(fetch_csv, write_csv, specs):
     print()
 
 
+def counters(paths):
+    acc, dur = defaultdict(lambda: defaultdict(list)), defaultdict(list)
+    names = []
+    for path in paths:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                key = (r['Kernel_Name'], int(r['Grid_Size']))
+                acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
+                if r['Counter_Name'] not in names:
+                    names.append(r['Counter_Name'])
+                dur[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    derived = ['mfma_busy_pct', 'wait_lds_pct', 'wait_any_pct', 'wait_inst_pct', 'active_pct', 'l2_hit_pct', 'fetch_MB', 'write_MB']
+    w = csv.writer(sys.stdout)
+    w.writerow(['Kernel_Name', 'Grid_Size', 'Dispatches', 'AvgNs_under_pmc'] + names + derived)
+    for key in sorted(acc, key=lambda k: -sum(dur[k])):
+        a = {n: (sum(v) / len(v)) for n, v in acc[key].items()}
+        ns = sum(dur[key]) / len(dur[key])
+        d = {}
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in a:
+            d['mfma_busy_pct'] = 100.0 * a['SQ_VALU_MFMA_BUSY_CYCLES'] / (ns * 2.4 * 256 * 4)
+        wc = a.get('SQ_WAVE_CYCLES')
+        if wc:
+            for col, cn in (('wait_lds_pct', 'SQ_WAIT_INST_LDS'), ('wait_any_pct', 'SQ_WAIT_ANY'), ('wait_inst_pct', 'SQ_WAIT_INST_ANY'),
+                            ('active_pct', 'SQ_ACTIVE_INST_ANY')):
+                if cn in a:
+                    d[col] = 100.0 * a[cn] / wc
+        if 'TCC_HIT_sum' in a and a['TCC_HIT_sum'] + a.get('TCC_MISS_sum', 0) > 0:
+            d['l2_hit_pct'] = 100.0 * a['TCC_HIT_sum'] / (a['TCC_HIT_sum'] + a['TCC_MISS_sum'])
+        if 'FETCH_SIZE' in a:
+            d['fetch_MB'] = 2 * a['FETCH_SIZE'] * 1024 / 1e6
+        if 'WRITE_SIZE' in a:
+            d['write_MB'] = a['WRITE_SIZE'] * 1024 / 1e6
+        n_disp = max(len(v) for v in acc[key].values())
+        w.writerow([key[0], key[1], n_disp, '%.0f' % ns] + ['%.6g' % a[n] if n in a else '' for n in names]
+                   + ['%.2f' % d[c] if c in d else '' for c in derived])
+
+
+def stamp(root=None):
+    """Evidence stamp: the commit and a content hash of the kernel sources a profile was taken on."""
+    import hashlib
+    import os
+    import subprocess
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for sub in ('anytime-3d-reconstruction_amd/csrc', 'include'):
+        d = os.path.join(root, sub)
+        for fn in sorted(os.listdir(d)):
+            if fn.endswith(('.hip', '.h')):
+                h.update(fn.encode())
+                h.update(open(os.path.join(d, fn), 'rb').read())
+    try:
+        head = subprocess.check_output(['git', '-C', root, 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        head = None
+    return {'git_head': head, 'csrc_sha256': h.hexdigest()}
+
+
 if __name__ == '__main__':
-    if len(sys.argv) >= 3 and sys.argv[1] == 'bygrid':
+    if len(sys.argv) >= 3 and sys.argv[1] == 'counters':
+        counters(sys.argv[2:])
+    elif len(sys.argv) >= 2 and sys.argv[1] == 'stamp':
+        json.dump(stamp(), sys.stdout)
+        print()
+    elif len(sys.argv) >= 3 and sys.argv[1] == 'bygrid':
         bygrid(sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == 'traffic':
         traffic(sys.argv[2], sys.argv[3], sys.argv[4:])

@@ -97,6 +97,45 @@ def test_convT3d_k4s2(L, dtname, B, side, cin, cout):
     _check(y, ref, dtname, 'convT3d_k4s2')
 
 
+# whole samples resident in LDS, padded taps skipped per MFMA row tile (skip_direct.hip); B = 5 / 9 leave a ragged last quad
+@pytest.mark.parametrize('act', [1, 0])
+@pytest.mark.parametrize('B,cin,cout', [(4, 128, 256), (5, 64, 64), (9, 256, 512), (33, 64, 128)])
+def test_conv3d_k4s2_skip(L, B, cin, cout, act):
+    rng = np.random.default_rng(B * 31 + cin)
+    x = _bf16_round(rng.standard_normal((B, 8, 8, 8, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cin, cout)) / np.sqrt(64 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    assert L.load().vv_conv3d_k4s2_skip_supported(8, cin, cout, L.VV_BF16)
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu' if act else None)
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4_skip', L.ptr(wd), L.ptr(wp), cin, cout, _st())
+    y = torch.full((B, 4, 4, 4, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_conv3d_k4s2_skip_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, 8, cin, cout, act, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'conv3d_k4s2_skip')
+
+
+@pytest.mark.parametrize('act', [1, 0])
+@pytest.mark.parametrize('B,cin,cout', [(4, 256, 128), (3, 64, 128), (6, 512, 256), (33, 128, 128)])
+def test_convT3d_k4s2_skip(L, B, cin, cout, act):
+    rng = np.random.default_rng(B * 17 + cin)
+    x = _bf16_round(rng.standard_normal((B, 4, 4, 4, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cout, cin)) / np.sqrt(8 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    assert L.load().vv_convT3d_k4s2_skip_supported(4, cin, cout, L.VV_BF16)
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu' if act else None)
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_skip', L.ptr(wd), L.ptr(wp), cin, cout, _st())
+    y = torch.full((B, 8, 8, 8, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_skip_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, 4, cin, cout, act, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'convT3d_k4s2_skip')
+
+
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(4, 64, 64), (7, 128, 16), (256, 128, 4096), (130, 4096, 64), (2, 64, 8200)])
 def test_dense(L, dtname, M, N, K):
