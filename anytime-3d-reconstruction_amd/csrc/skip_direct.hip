@@ -26,6 +26,8 @@
 //               during the previous unit; fragment reads are inline asm one step ahead of their MFMAs with counted lgkmcnt.
 //   workgroups: (batch / 4) x (Cout / 64) for conv, (batch / 4) x 4 parity pairs x (Cout / 128) for convT; ordered so that
 //               the groups of one sample quad run on one XCD.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -36,9 +38,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned sd_u4;
 
 constexpr int SD_ATILE = 256 * 128;        // [4 s][4][4][4] rows x 128 B
 constexpr int SD_WST = 32768;              // one weight stage
-constexpr int SD_W0 = 2 * SD_ATILE;        // weight ring behind the two A buffers
-constexpr int SD_ZERO = SD_W0 + 2 * SD_WST;   // 256 B of zeros: the row every out-of-grid w lane reads
-constexpr int SD_LDS = SD_ZERO + 256;      // 131,328 B
+constexpr int SD_A0 = 4096;                // slack in front of the A buffers: a skipped tile's fragment read may reach 2.5 KiB below its tile
+constexpr int SD_W0 = SD_A0 + 2 * SD_ATILE;   // weight ring behind the two A buffers
+constexpr int SD_ZERO = SD_W0 + 2 * SD_WST;   // 4 KiB of zeros: what every out-of-grid w lane reads (base + the tap's immediate offset)
+constexpr int SD_LDS = SD_ZERO + 4096;     // 139,264 B
 constexpr int SD_XCH = 0;                  // conv epilogue: K-half exchange [8 waves][8][64 lanes] f32x4 = 64 KiB
 constexpr int SD_OST = 65536;              // conv epilogue: [256 rows][144 B] output staging
 constexpr int SD_OPITCH = 144;
@@ -54,6 +57,8 @@ struct SdArgs {
     int batch, cin, cout, act;
     unsigned x_bytes, w_bytes;
     int groups;                            // workgroups per sample quad
+    int dbg;                               // timing ablations (VV_SD_DBG): 1 = no weight DMA after the ring is primed, 2 = no A DMA after the
+                                           // first two tiles, 4 = no MFMAs -- wrong results, diagnostics only
 };
 
 // out[((t*NC + c)*cout + n)*64 + k] = w[(t*cin + c*64 + k)*cout + n]          (Keras Conv3D [kd,kh,kw,Cin,Cout])
@@ -119,66 +124,75 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
     const u32x4 rsx = vv_make_rsrc(a.x, a.x_bytes), rsw = vv_make_rsrc(a.w, a.w_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
-    if (tid < 16) reinterpret_cast<uint4 *>(smem + SD_ZERO)[tid] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 256; i += 512) reinterpret_cast<uint4 *>(smem + SD_ZERO)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     // ---- producers.  A tile row R = ((s*4 + jd)*4 + jh)*4 + jw, slot swizzle f(R) = ((s & 1) << 2) | (jw & 2): with
     // R & 1 = jw & 1 the 16 lanes of every ds_read_b128 lane group (rows {0-3,12-15} of k-quarter kq, rows {4-11} of kq ^ 1)
     // land on 16 different 16-byte bank positions.  The swizzle is applied to the SOURCE slot; LDS is written linearly.
-    auto issue_a = [&](int T, int k) {            // piece k (0..3) of this wave for tile T into buffer T & 1
+    // Per piece the lane part of the source offset is prepared once; what changes per tile / unit rides in soffset.
+    unsigned a_lane[4], w_lane[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
         const int it = wave * 4 + k;
         const int R = it * 8 + (lane >> 3);
         const int s = R >> 6, jd = (R >> 4) & 3, jh = (R >> 2) & 3, jw = R & 3;
-        const int f = ((s & 1) << 2) | (jw & 2);
-        const int slot = (lane & 7) ^ f;
-        unsigned vo;
+        const int slot = (lane & 7) ^ (((s & 1) << 2) | (jw & 2));
+        if (MODE == 0) a_lane[k] = (unsigned)(((((b0 + s) * 8 + 2 * jd) * 8 + 2 * jh) * 8 + 2 * jw) * (a.cin * 2) + slot * 16);
+        else a_lane[k] = (unsigned)((((b0 + s) * 64) + (R & 63)) * (a.cin * 2) + slot * 16);
+        // weight rows n of a stage: slot swizzle (n >> 1) & 7 (the implicit GEMM's, conflict-free for consecutive rows)
+        const int blk = MODE == 0 ? (it & 7) : (it & 15);
+        const int nrow = blk * 8 + (lane >> 3);
+        w_lane[k] = (unsigned)(nrow * 128 + (((lane & 7) ^ ((nrow >> 1) & 7)) << 4));
+    }
+    // conv tiles are numbered T = q * NC + c (phase, 64-channel chunk); the callers carry (q, c) along so that no integer
+    // division sits in the loop (tq = q, tc = c; unused for convT, whose tile IS the chunk)
+    auto issue_a = [&](int T, int tq, int tc) {   // the 4 pieces of this wave for tile T into buffer T & 1
+        unsigned soff;
         if (MODE == 0) {
-            const int q = T / NC, c = T - q * NC;
-            const int xd = 2 * jd + 1 - ((q >> 2) & 1), xh = 2 * jh + 1 - ((q >> 1) & 1), xw = 2 * jw + 1 - (q & 1);
-            vo = (unsigned)(((((b0 + s) * 8 + xd) * 8 + xh) * 8 + xw) * (a.cin * 2) + c * 128 + slot * 16);
+            const int q = tq, c = tc;
+            soff = (unsigned)(((1 - ((q >> 2) & 1)) * 64 + (1 - ((q >> 1) & 1)) * 8 + (1 - (q & 1))) * (a.cin * 2) + c * 128);
         } else {
-            vo = (unsigned)((((b0 + s) * 64) + (R & 63)) * (a.cin * 2) + T * 128 + slot * 16);
+            soff = (unsigned)(T * 128);
         }
-        vv_dma16(rsx, vo, lds0 + (T & 1) * SD_ATILE + it * 1024);
-    };
-    // weight rows n of a stage: slot swizzle (n >> 1) & 7 (the implicit GEMM's, conflict-free for consecutive rows)
-    auto issue_w = [&](int u) {                   // the 4 pieces of this wave for unit u into ring[u & 1]
-        const unsigned st = lds0 + SD_W0 + (u & 1) * SD_WST;
+        soff = __builtin_amdgcn_readfirstlane(soff);       // wave-uniform by construction (the division by NC goes through the vector unit)
+        const unsigned dst = lds0 + SD_A0 + (T & 1) * SD_ATILE + wave * 4096;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int it = wave * 4 + k;
-            unsigned src, nrow;
-            if (MODE == 0) {
-                const int T = u >> 1, ad = u & 1;
-                const int q = T / NC, c = T - q * NC;
-                const int j = it >> 3, blk = it & 7;                       // tap j of the unit, 8-row block
-                const int td = 2 * ad + ((q >> 2) & 1), th = 2 * (j >> 1) + ((q >> 1) & 1), tw = 2 * (j & 1) + (q & 1);
-                const int t = (td * 4 + th) * 4 + tw;
-                nrow = blk * 8 + (lane >> 3);
-                src = (unsigned)(((t * NC + c) * a.cout + ng * 64) * 128);
-            } else {
-                const int c = u >> 3, ta = u & 7;
-                const int pi = it >> 4, blk = it & 15;
-                const int p = pd * 4 + ph * 2 + pi;
-                nrow = blk * 8 + (lane >> 3);
-                src = (unsigned)((((p * 8 + ta) * NC + c) * a.cout + ng * 128) * 128);
-            }
-            const unsigned slot = (lane & 7) ^ ((nrow >> 1) & 7);
-            vv_dma16(rsw, src + nrow * 128 + slot * 16, st + it * 1024);
+        for (int k = 0; k < 4; ++k) vv_dma16(rsx, a_lane[k], soff, dst + k * 1024);
+    };
+    auto issue_w = [&](int u, int tq, int tc) {   // the 4 pieces of this wave for unit u into ring[u & 1]
+        unsigned soff;
+        if (MODE == 0) {
+            const int ad = u & 1;
+            const int q = tq, c = tc;
+            const int j = wave >> 1;                                       // this wave's pieces belong to tap j of the unit
+            const int td = 2 * ad + ((q >> 2) & 1), th = 2 * (j >> 1) + ((q >> 1) & 1), tw = 2 * (j & 1) + (q & 1);
+            const int t = (td * 4 + th) * 4 + tw;
+            soff = (unsigned)(((t * NC + c) * a.cout + ng * 64) * 128);
+        } else {
+            const int c = u >> 3, ta = u & 7;
+            const int p = pd * 4 + ph * 2 + hv;                            // this wave's pieces belong to its own parity
+            soff = (unsigned)((((p * 8 + ta) * NC + c) * a.cout + ng * 128) * 128);
         }
+        soff = __builtin_amdgcn_readfirstlane(soff);
+        const unsigned dst = lds0 + SD_W0 + (u & 1) * SD_WST + wave * 4096;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vv_dma16(rsw, w_lane[k], soff, dst + k * 1024);
     };
 
-    // ---- consumer addressing
+    // ---- consumer addressing.  A fragment read = per-lane base (tile, w variant, k-step) + an immediate (the tap's d / h
+    // offset): no address arithmetic in the loop.
     const int r = lane & 15, kq = lane >> 4, ls = r >> 2, lw = r & 3;
     auto arow = [&](int jw, int ks) -> unsigned {       // (s, jd = 0, jh = 0, jw), k-step ks: byte offset inside an A tile
         const int f = ((ls & 1) << 2) | (jw & 2);
         return (unsigned)((ls * 64 + jw) * 128 + ((((ks << 2) | kq) ^ f) << 4));
     };
-    const unsigned zaddr = lds0 + SD_ZERO + kq * 16;
-    // weight fragment: row n = lane & 15 of a 16-channel tile, k-quarter kq
+    // weight fragment: row n = lane & 15 of a 16-channel tile, k-quarter kq; conv waves read one k-step (their K half)
     unsigned wb[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) wb[ks] = lds0 + SD_W0 + (unsigned)(r * 128 + ((((ks << 2) | kq) ^ ((r >> 1) & 7)) << 4));
+    const unsigned wbc = hv ? wb[1] : wb[0];                 // conv
+    const unsigned wbt0 = wb[0] + (unsigned)(hv * 16384), wbt1 = wb[1] + (unsigned)(hv * 16384);   // convT: this wave's parity
 
     // row tiles of this wave: (d, h) = (i, (i + mq) & 3)
     int td_[4], th_[4];
@@ -192,20 +206,7 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // One step: 4 x fragments (row tiles) + 4 weight fragments (channel tiles nt0..nt0+3) -> up to 16 MFMAs.
-    // dd, dh = the tap's cell offset in d / h (-1, 0, +1); tiles whose d / h index leaves 0..3 are skipped (their fragment is
-    // still read, from the tile's own cell, so that the lgkmcnt counts stay static).  The w offset is folded into `base`
-    // (a per-lane byte offset prepared per tap variant); lanes whose w index leaves the grid read the zero row.
-    auto x_addr = [&](int i, unsigned abuf, int dd, int dh, unsigned base, bool wok, int &vmask) -> unsigned {
-        const int jd = td_[i] + dd, jh = th_[i] + dh;
-        const bool valid = (unsigned)jd < 4u && (unsigned)jh < 4u;
-        vmask |= valid ? (1 << i) : 0;
-        const int od = valid ? jd : td_[i], oh = valid ? jh : th_[i];
-        const unsigned real = base + (abuf + (unsigned)(od * 2048 + oh * 512));
-        return wok ? real : zaddr;
-    };
     auto mma16 = [&](const sd_u4 *xf, const sd_u4 *wf, int nt0, int vmask) {
-        vmask = __builtin_amdgcn_readfirstlane(vmask);   // wave-uniform by construction: keep the tile tests on the scalar unit
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (vmask & (1 << i)) {
@@ -217,102 +218,199 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
             }
         }
     };
-
-    // convT: the w offset of a tap is hv - aw, fixed per wave: aw = 0 -> w + hv, aw = 1 -> w + hv - 1
-    const int tjw0 = lw + hv, tjw1 = lw + hv - 1;
-    const unsigned tb0[2] = {arow(tjw0 & 3, 0), arow(tjw0 & 3, 1)}, tb1[2] = {arow(tjw1 & 3, 0), arow(tjw1 & 3, 1)};
-    const bool tok0 = (unsigned)tjw0 < 4u, tok1 = (unsigned)tjw1 < 4u;
+    // tiles whose cell index i + off stays inside 0..3, as a 4-bit mask over the wave's tiles
+    auto tile_mask = [&](const int *cell, int off) -> int {
+        int m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m |= ((unsigned)(cell[i] + off) < 4u) ? (1 << i) : 0;
+        return __builtin_amdgcn_readfirstlane(m);
+    };
 
     const int ntiles = MODE == 0 ? 8 * NC : NC;         // A tiles
-    const int upt = MODE == 0 ? 2 : 8;                  // units per A tile
-    const int nunits = ntiles * upt;
+    const int nunits = ntiles * (MODE == 0 ? 2 : 8);
 
-    // ---- prologue
-#pragma unroll
-    for (int k = 0; k < 4; ++k) issue_a(0, k);
-    issue_w(0);
+    // Pipeline.  A unit's barrier sits in front of its LAST MFMA block: by then every fragment of the unit has returned (its
+    // weight stage and, at the end of a tile, the A buffer are free for the DMA two units / tiles ahead), the stage of the next
+    // unit has landed, and the first fragment reads of the next unit are issued before that last block runs -- the matrix
+    // pipe never drains at a barrier.
+    // (q, c) of conv tile 1: chunk 1 of phase 0, or phase 1 when a phase has one chunk
+    const int q1_ = NC > 1 ? 0 : 1, c1_ = NC > 1 ? 1 : 0;
+    issue_a(0, 0, 0);
+    issue_w(0, 0, 0);
+    if (ntiles > 1) issue_a(1, q1_, c1_); else issue_a(0, 0, 0);   // (a single-tile layer re-stages tile 0: the count below stays fixed)
+    issue_w(1, 0, 0);                                       // unit 1: conv (tile 0, ad 1) / convT (chunk 0, tap 1)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // A(0), W(0) landed; A(1), W(1) (4 pieces each, younger) may fly on
+    __builtin_amdgcn_s_barrier();
 
-#pragma unroll 1
-    for (int u = 0; u < nunits; ++u) {
-        const int T = MODE == 0 ? (u >> 1) : (u >> 3);
-        const int first = MODE == 0 ? ((u & 1) == 0) : ((u & 7) == 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (u + 1 < nunits) issue_w(u + 1);
-        if (first && T + 1 < ntiles) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) issue_a(T + 1, k);
-        }
-        const unsigned abuf = lds0 + (T & 1) * SD_ATILE;
-        const unsigned wst = (u & 1) * SD_WST;
-        sd_u4 xP[4], xQ[4], wP[4], wQ[4];
-        int vP = 0, vQ = 0;
-        if constexpr (MODE == 0) {
-            // unit = taps (ad = u & 1, ah, aw), this wave's k-step hv of the 64-channel chunk
-            const int q = T / NC;
+    // zero target of an out-of-grid w lane: the bank position of the (wrapped) row it would have read -> conflict-free
+    auto zrow = [&](int jw, int ks) -> unsigned { return lds0 + SD_ZERO + (arow(jw & 3, ks) & 255u); };
+
+    sd_u4 xP[4], xQ[4], wP[4], wQ[4];
+    if constexpr (MODE == 0) {
+        // the three w variants of a lane: w - 1, w, w + 1 (k-step hv of the chunk)
+        const unsigned lm1 = arow((lw - 1) & 3, hv), l00 = arow(lw, hv), lp1 = arow((lw + 1) & 3, hv);
+        const unsigned zm1 = zrow(lw - 1, hv), zp1 = zrow(lw + 1, hv);
+        const bool okm1 = lw >= 1, okp1 = lw <= 2;
+        unsigned xb0[4], xb1[4];                    // aw = 0 / 1 bases of the CURRENT tile
+        int dm0, dm1, hm0, hm1;
+        // tap (ad, ah, aw) of phase q reads cell (d + ad - 1 + qd, h + ah - 1 + qh, w + aw - 1 + qw)
+        auto setup = [&](int T, int q) {
             const int qd = (q >> 2) & 1, qh = (q >> 1) & 1, qw = q & 1;
-            const int dd = (u & 1) - (1 - qd);
-            // per-lane bases of the two w variants of this phase: aw = 0 -> w - (1 - qw), aw = 1 -> w + qw
-            const int jw0 = lw - (1 - qw), jw1 = lw + qw;
-            const unsigned xb0 = arow(jw0 & 3, hv), xb1 = arow(jw1 & 3, hv);
-            const bool ok0 = (unsigned)jw0 < 4u, ok1 = (unsigned)jw1 < 4u;
-            const unsigned wsel0 = (hv ? wb[1] : wb[0]) + wst;
-            auto rd = [&](int j, sd_u4 *xf, sd_u4 *wf, int &vv) {
-                const int dh = (j >> 1) - (1 - qh);
-                vv = 0;
+            const unsigned abuf = lds0 + SD_A0 + (T & 1) * SD_ATILE;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned ad_ = x_addr(i, abuf, dd, dh, (j & 1) ? xb1 : xb0, (j & 1) ? ok1 : ok0, vv);
-                    SD_RD(xf[i], ad_, 0);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned sc_ = abuf + (unsigned)((td_[i] - 1 + qd) * 2048 + (th_[i] - 1 + qh) * 512);
+                xb0[i] = qw ? l00 + sc_ : (okm1 ? lm1 + sc_ : zm1);
+                xb1[i] = qw ? (okp1 ? lp1 + sc_ : zp1) : l00 + sc_;
+            }
+            dm0 = tile_mask(td_, qd - 1); dm1 = tile_mask(td_, qd); hm0 = tile_mask(th_, qh - 1); hm1 = tile_mask(th_, qh);
+            if (a.dbg & 4) dm0 = dm1 = 0;
+        };
+        // step j = (ah, aw) of unit AD: x fragments at immediate AD*2048 + ah*512, weight tiles at AD*32768 (ring stage) +
+        // j*8192 (tap) + nt*2048
+#define SD_CONV_RD(AD, J, XF, WF)                                                                                           \
+    do {                                                                                                                    \
+        constexpr int XO = (AD) * 2048 + ((J) >> 1) * 512, WO = (AD) * SD_WST + (J) * 8192;                                 \
+        if ((J) & 1) { SD_RD(XF[0], xb1[0], XO); SD_RD(XF[1], xb1[1], XO); SD_RD(XF[2], xb1[2], XO); SD_RD(XF[3], xb1[3], XO); } \
+        else { SD_RD(XF[0], xb0[0], XO); SD_RD(XF[1], xb0[1], XO); SD_RD(XF[2], xb0[2], XO); SD_RD(XF[3], xb0[3], XO); }     \
+        SD_RD(WF[0], wbc, WO); SD_RD(WF[1], wbc, WO + 2048); SD_RD(WF[2], wbc, WO + 4096); SD_RD(WF[3], wbc, WO + 6144);    \
+    } while (0)
+        setup(0, 0);
+        SD_CONV_RD(0, 0, xP, wP);
+        int qa = 0, ca = 0;                             // (q, c) of tile T, T + 1, T + 2
+        int qb = q1_, cb = c1_;
+        int qc = cb + 1 < NC ? qb : qb + 1, cc = cb + 1 < NC ? cb + 1 : 0;
+#pragma unroll 1
+        for (int T = 0; T < ntiles; ++T) {
+            // ---- unit AD = 0
+            {
+                const int u = 2 * T;
+                SD_CONV_RD(0, 1, xQ, wQ);
+                SD_WAIT8(8, xP, wP);
+                mma16(xP, wP, 0, dm0 & hm0);
+                SD_CONV_RD(0, 2, xP, wP);
+                SD_WAIT8(8, xQ, wQ);
+                mma16(xQ, wQ, 0, dm0 & hm0);
+                SD_CONV_RD(0, 3, xQ, wQ);
+                SD_WAIT8(8, xP, wP);
+                mma16(xP, wP, 0, dm0 & hm1);
+                SD_WAIT8(0, xQ, wQ);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, qb, cb);
+                SD_CONV_RD(1, 0, xP, wP);
+                mma16(xQ, wQ, 0, dm0 & hm1);
+            }
+            // ---- unit AD = 1
+            {
+                const int u = 2 * T + 1;
+                SD_CONV_RD(1, 1, xQ, wQ);
+                SD_WAIT8(8, xP, wP);
+                mma16(xP, wP, 0, dm1 & hm0);
+                SD_CONV_RD(1, 2, xP, wP);
+                SD_WAIT8(8, xQ, wQ);
+                mma16(xQ, wQ, 0, dm1 & hm0);
+                SD_CONV_RD(1, 3, xQ, wQ);
+                SD_WAIT8(8, xP, wP);
+                mma16(xP, wP, 0, dm1 & hm1);
+                SD_WAIT8(0, xQ, wQ);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, qb, cb);
+                if (T + 2 < ntiles && !(a.dbg & 2)) issue_a(T + 2, qc, cc);
+                const int lastmask = dm1 & hm1;
+                if (T + 1 < ntiles) {
+                    setup(T + 1, qb);
+                    SD_CONV_RD(0, 0, xP, wP);
                 }
-                const unsigned wsel = wsel0 + (unsigned)(j * 8192);
-                SD_RD(wf[0], wsel, 0);
-                SD_RD(wf[1], wsel, 2048);
-                SD_RD(wf[2], wsel, 4096);
-                SD_RD(wf[3], wsel, 6144);
-            };
-            rd(0, xP, wP, vP);
-            rd(1, xQ, wQ, vQ);
-            SD_WAIT8(8, xP, wP);
-            mma16(xP, wP, 0, vP);
-            rd(2, xP, wP, vP);
-            SD_WAIT8(8, xQ, wQ);
-            mma16(xQ, wQ, 0, vQ);
-            rd(3, xQ, wQ, vQ);
-            SD_WAIT8(8, xP, wP);
-            mma16(xP, wP, 0, vP);
-            SD_WAIT8(0, xQ, wQ);
-            mma16(xQ, wQ, 0, vQ);
-        } else {
-            // unit = tap a = u & 7 of this wave's parity (pd, ph, hv): both k-steps x two channel halves
-            const int ta = u & 7;
-            const int dd = pd - ((ta >> 2) & 1), dh = ph - ((ta >> 1) & 1);
-            const unsigned wbase0 = wb[0] + wst + (unsigned)(hv * 16384), wbase1 = wb[1] + wst + (unsigned)(hv * 16384);
-            const bool aw = ta & 1;
-            auto rdx = [&](int ks, sd_u4 *xf, int &vv) {
-                vv = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned ad_ = x_addr(i, abuf, dd, dh, aw ? tb1[ks] : tb0[ks], aw ? tok1 : tok0, vv);
-                    SD_RD(xf[i], ad_, 0);
-                }
-            };
-            // weight fragments of channel tiles 0..3 / 4..7
-            rdx(0, xP, vP);
-            SD_RD(wP[0], wbase0, 0); SD_RD(wP[1], wbase0, 2048); SD_RD(wP[2], wbase0, 4096); SD_RD(wP[3], wbase0, 6144);
-            SD_RD(wQ[0], wbase0, 8192); SD_RD(wQ[1], wbase0, 10240); SD_RD(wQ[2], wbase0, 12288); SD_RD(wQ[3], wbase0, 14336);
-            SD_WAIT8(4, xP, wP);                    // x (k-step 0) and channel tiles 0..3 are in
-            mma16(xP, wP, 0, vP);
-            rdx(1, xQ, vQ);
-            SD_RD(wP[0], wbase1, 0); SD_RD(wP[1], wbase1, 2048); SD_RD(wP[2], wbase1, 4096); SD_RD(wP[3], wbase1, 6144);
-            SD_WAIT8(8, xP, wQ);                    // channel tiles 4..7 of k-step 0
-            mma16(xP, wQ, 4, vP);
-            SD_RD(wQ[0], wbase1, 8192); SD_RD(wQ[1], wbase1, 10240); SD_RD(wQ[2], wbase1, 12288); SD_RD(wQ[3], wbase1, 14336);
-            SD_WAIT8(4, xQ, wP);
-            mma16(xQ, wP, 0, vQ);
-            SD_WAIT8(0, xQ, wQ);
-            mma16(xQ, wQ, 4, vQ);
+                mma16(xQ, wQ, 0, lastmask);
+            }
+            qa = qb; ca = cb; qb = qc; cb = cc;
+            qc = cb + 1 < NC ? qb : qb + 1; cc = cb + 1 < NC ? cb + 1 : 0;
+            (void)qa; (void)ca;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef SD_CONV_RD
+    } else {
+        // tap (ad, ah, aw) of parity (pd, ph, hv) reads cell (d + pd - ad, h + ph - ah, w + hv - aw)
+        const int jw0 = lw + hv, jw1 = lw + hv - 1;        // aw = 0 / 1
+        const unsigned l0[2] = {arow(jw0 & 3, 0), arow(jw0 & 3, 1)}, l1[2] = {arow(jw1 & 3, 0), arow(jw1 & 3, 1)};
+        const unsigned z0[2] = {zrow(jw0, 0), zrow(jw0, 1)}, z1[2] = {zrow(jw1, 0), zrow(jw1, 1)};
+        const bool ok0 = (unsigned)jw0 < 4u, ok1 = (unsigned)jw1 < 4u;
+        int dmA[2] = {tile_mask(td_, pd), tile_mask(td_, pd - 1)};                          // [ad]
+        const int hmA[2] = {tile_mask(th_, ph), tile_mask(th_, ph - 1)};                    // [ah]
+        if (a.dbg & 4) dmA[0] = dmA[1] = 0;
+        unsigned xb[2][2][4];                        // [aw][k-step][tile] of the CURRENT tile; immediate (1 - ad)*2048 + (1 - ah)*512 on top
+        auto setup = [&](int T) {
+            const unsigned abuf = lds0 + SD_A0 + (T & 1) * SD_ATILE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned sc_ = abuf + (unsigned)((td_[i] + pd - 1) * 2048 + (th_[i] + ph - 1) * 512);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    xb[0][ks][i] = ok0 ? l0[ks] + sc_ : z0[ks];
+                    xb[1][ks][i] = ok1 ? l1[ks] + sc_ : z1[ks];
+                }
+            }
+        };
+#define SD_T_X(A, KS, XF)                                                                                                   \
+    do {                                                                                                                    \
+        constexpr int XO = (1 - (((A) >> 2) & 1)) * 2048 + (1 - (((A) >> 1) & 1)) * 512;                                    \
+        SD_RD(XF[0], xb[(A) & 1][KS][0], XO); SD_RD(XF[1], xb[(A) & 1][KS][1], XO);                                         \
+        SD_RD(XF[2], xb[(A) & 1][KS][2], XO); SD_RD(XF[3], xb[(A) & 1][KS][3], XO);                                         \
+    } while (0)
+#define SD_T_W(A, WB, HI, WF)                                                                                               \
+    do {                                                                                                                    \
+        constexpr int WO = ((A) & 1) * SD_WST + (HI) * 8192;                                                                \
+        SD_RD(WF[0], WB, WO); SD_RD(WF[1], WB, WO + 2048); SD_RD(WF[2], WB, WO + 4096); SD_RD(WF[3], WB, WO + 6144);       \
+    } while (0)
+        setup(0);
+        SD_T_X(0, 0, xP); SD_T_W(0, wbt0, 0, wP);
+#pragma unroll 1
+        for (int T = 0; T < ntiles; ++T) {
+            // unit = tap A of this wave's parity: blocks (k-step 0: channel tiles 0..3, 4..7), (k-step 1: 0..3, 4..7); entered
+            // with xP (k-step 0) and wP (k-step 0, tiles 0..3) in flight
+            auto unit = [&](auto a_c) {
+                constexpr int A = decltype(a_c)::value;
+                constexpr int AD = (A >> 2) & 1, AH = (A >> 1) & 1, AN = (A + 1) & 7;
+                const int u = 8 * T + A;
+                const int vm = dmA[AD] & hmA[AH];
+                SD_T_W(A, wbt0, 1, wQ);
+                SD_WAIT8(4, xP, wP);
+                mma16(xP, wP, 0, vm);
+                SD_T_X(A, 1, xQ); SD_T_W(A, wbt1, 0, wP);
+                SD_WAIT8(8, xP, wQ);
+                mma16(xP, wQ, 4, vm);
+                SD_T_W(A, wbt1, 1, wQ);
+                SD_WAIT8(4, xQ, wP);
+                mma16(xQ, wP, 0, vm);
+                SD_WAIT8(0, xQ, wQ);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, 0, 0);
+                if (A == 7) {
+                    if (T + 2 < ntiles && !(a.dbg & 2)) issue_a(T + 2, 0, 0);
+                    if (T + 1 < ntiles) {
+                        setup(T + 1);
+                        SD_T_X(AN, 0, xP); SD_T_W(AN, wbt0, 0, wP);
+                    }
+                } else {
+                    SD_T_X(AN, 0, xP); SD_T_W(AN, wbt0, 0, wP);
+                }
+                mma16(xQ, wQ, 4, vm);
+            };
+            unit(std::integral_constant<int, 0>{});
+            unit(std::integral_constant<int, 1>{});
+            unit(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 3>{});
+            unit(std::integral_constant<int, 4>{});
+            unit(std::integral_constant<int, 5>{});
+            unit(std::integral_constant<int, 6>{});
+            unit(std::integral_constant<int, 7>{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef SD_T_X
+#undef SD_T_W
     }
     __builtin_amdgcn_s_barrier();                  // every fragment read has returned: the stages are free
 
@@ -460,6 +558,7 @@ int sd_launch(const void *x, const void *w, const float *scale, const float *shi
         a.x_bytes = (unsigned)((size_t)nb * sample_in);
         a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
         a.groups = MODE == 0 ? cout / 64 : 4 * (cout / 128);
+        { const char *e = getenv("VV_SD_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int nsg = (nb + 3) / 4;
         VV_LAUNCH(sd_kernel<MODE>, dim3(nsg * a.groups), dim3(512), SD_LDS, st, a);
         const int rc = vv_launch_status();

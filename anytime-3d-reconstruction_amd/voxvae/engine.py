@@ -214,6 +214,13 @@ class EncoderEngine(_EngineBase):
                 self.packed['q%d' % i] = True
                 if self.packed['scale%d' % i] is not None:
                     self.packed['scale%d' % i].mul_(qs)
+            elif (self._want_fold and not os.environ.get('VV_NO_SKIP')
+                  and L.load().vv_conv3d_k4s2_skip_supported(self.D >> i, f[i - 1], f[i], self.dt)):
+                # the 8^3 -> 4^3 layer: whole samples resident in LDS, padded taps skipped (inference path; the training step
+                # keeps the implicit-GEMM panel above, which also serves its data-gradient passes)
+                ws = self._empty(64 * f[i - 1] * f[i])
+                L.call('vv_pack_conv_k4_skip', L.ptr(p['conv%d/kernel' % i]), L.ptr(ws), f[i - 1], f[i], st)
+                self.packed['ws%d' % i] = ws
         i = len(f) - 1
         q = self.fp8 and (self.S ** 3 * f[i - 1]) % 128 == 0
         wk = p['conv%d/kernel' % i]
@@ -254,6 +261,11 @@ class EncoderEngine(_EngineBase):
                     ws = self.ws.get(L.load().vv_conv3d_k4s2_workspace_bytes(B, side, f[i - 1], f[i], L.VV_FP8))
                     self._call(name, 'vv_conv3d_k4s2_fwd_io', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk['scale%d' % i]), L.ptr(pk['shift%d' % i]),
                                L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
+                hdt = odt
+            elif ('ws%d' % i) in pk and not nq:
+                o = self._empty(B, side // 2, side // 2, side // 2, f[i])
+                self._call(name, 'vv_conv3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
                 hdt = odt
             elif not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
@@ -353,6 +365,11 @@ class DecoderEngine(_EngineBase):
             elif direct:
                 pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
+            elif (self._want_fold and not os.environ.get('VV_NO_SKIP')
+                  and L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)):
+                # the 4^3 -> 8^3 layer (see the encoder's twin)
+                pk['ws%d' % i] = self._empty(64 * f[i - 1] * f[i])
+                L.call('vv_pack_convT_k4s2_skip', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['ws%d' % i]), f[i - 1], f[i], st)
 
     def forward(self, z_act, target=None, want_logits=False, gamma=0.6, epsilon=1e-7):
         """z_act: [B,L] in the activation dtype.  target: float32 [B,D,D,D,1] or None.
@@ -381,6 +398,12 @@ class DecoderEngine(_EngineBase):
             if ('wf%d' % i) in pk:
                 o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
                 self._call(name, 'vv_convT3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['wf%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                h, side, hdt = o, 2 * side, self.dt
+                continue
+            if ('ws%d' % i) in pk and not nq and hdt == self.dt:
+                o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+                self._call(name, 'vv_convT3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
                            L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
                 h, side, hdt = o, 2 * side, self.dt
                 continue

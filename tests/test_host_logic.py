@@ -211,3 +211,36 @@ def test_default_dtype_switch_accepts_the_three_modes():
         voxvae.set_default_dtype(keep)
     from voxvae import lib as L
     assert (L.DTYPES['f32'], L.DTYPES['bf16'], L.DTYPES['fp8']) == (L.VV_F32, L.VV_BF16, L.VV_FP8) == (0, 1, 2)   # include/voxvae.h vv_dtype
+
+
+def _run_bench(*args, timeout=300):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          env=env, text=True, timeout=timeout)
+
+
+def test_bench_self_launches_two_ranks_and_reduces_metrics_gloo():
+    """bench.py --gpus 2 outside a launcher must start the two ranks itself and relay rank 0's line: rehearsed on the CPU
+    with the gloo backend (--dry-run: no kernel runs, the launcher, the SUM of the 8 metric scalars and the MAX of the timed
+    region are the real code; reference DP semantics AE3D.py:92-104)."""
+    import json
+    p = _run_bench('--gpus', '2', '--dry-run', '--backend', 'gloo', '--steps', '5', '--warmup', '1')
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # ONE JSON line, from rank 0
+    got = json.loads(lines[0])
+    assert got['n_gpus'] == 2 and got['rccl_world_size'] == 2 and got['dry_run'] is True
+    # rank r fabricates sum_bce = 10 (r + 1) B over B samples, elapsed = steps (1 + r) ms: SUM / MAX over the ranks
+    assert got['global_metrics']['samples'] == 512 and abs(got['global_metrics']['loss_shape'] - 15.0) < 1e-9
+    assert abs(got['ms_per_step'] - 2.0) < 1e-9
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N with fewer than N visible GPUs fails loudly instead of running one rank (no GPU exists in this container)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs are visible here')
+    p = _run_bench('--gpus', '2', '--steps', '1', timeout=120)
+    assert p.returncode != 0
+    assert '2 GPUs requested, %d visible' % torch.cuda.device_count() in (p.stderr + p.stdout)
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
