@@ -697,6 +697,60 @@ __global__ __launch_bounds__(64) void final_reduce_kernel(const float *__restric
     if (lane == 0) *reinterpret_cast<f32x4 *>(stats + (size_t)b * 4) = f32x4{s[0], s[1], s[2], s[3]};
 }
 
+// final_reduce + shape_metrics (nolbo.py:1498-1501) in ONE launch for the usual case of a few partial blocks per sample: thread
+// b sums its sample's partials in block order (as final_reduce does), keeps (bce, TP/(TP+FP+1e-10), TP/(TP+FN+1e-10), IoU), and
+// the batch means are formed by a fixed tree (wave shuffles, then the waves in order): deterministic, independent of timing.
+__global__ __launch_bounds__(256) void final_reduce_metrics_kernel(const float *__restrict__ partials, float *__restrict__ stats,
+                                                                   float *__restrict__ out4, int nblk, int batch) {
+    __shared__ float red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < batch; b += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nblk; ++i) s += *reinterpret_cast<const f32x4 *>(partials + ((size_t)b * nblk + i) * 4);
+        *reinterpret_cast<f32x4 *>(stats + (size_t)b * 4) = s;
+        const float tp = s[1], fp = s[2], fn = s[3];
+        m[0] += s[0];
+        m[1] += tp / (tp + fp + 1e-10f);
+        m[2] += tp / (tp + fn + 1e-10f);
+        m[3] += tp / fmaxf(tp + fp + fn, 1.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = vv_wave_sum(m[k]);
+    if (lane == 0) { red[wave][0] = m[0]; red[wave][1] = m[1]; red[wave][2] = m[2]; red[wave][3] = m[3]; }
+    __syncthreads();
+    if (tid < 4) out4[tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)batch;
+}
+
+__global__ __launch_bounds__(64) void final_metrics_kernel(const float *__restrict__ stats, float *__restrict__ out4, int batch) {
+    const int lane = threadIdx.x;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = lane; b < batch; b += 64) {
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(stats + (size_t)b * 4);
+        const float tp = s[1], fp = s[2], fn = s[3];
+        m[0] += s[0];
+        m[1] += tp / (tp + fp + 1e-10f);
+        m[2] += tp / (tp + fn + 1e-10f);
+        m[3] += tp / fmaxf(tp + fp + fn, 1.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = vv_wave_sum(m[k]);
+    if (lane < 4) out4[lane] = (lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3]) / (float)batch;
+}
+
+// per-sample sums from the partial blocks, and the batch metrics when the caller wants them
+void finish_stats(const float *partials, float *stats, float *metrics4, int nblk, int batch, hipStream_t st) {
+    if (metrics4 && nblk <= 64) {
+        VV_LAUNCH(final_reduce_metrics_kernel, dim3(1), dim3(256), 0, st, partials, stats, metrics4, nblk, batch);
+        return;
+    }
+    VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
+    if (metrics4) VV_LAUNCH(final_metrics_kernel, dim3(1), dim3(64), 0, st, stats, metrics4, batch);
+}
+
+int final_bce_impl(const void *x, const float *w_keras, const float *target, float *probs, float *logits, float *stats, float *metrics4,
+                   int batch, int side, int cin, float gamma, float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 }  // namespace
 
 VV_EXPORT size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side) {
@@ -707,6 +761,21 @@ VV_EXPORT size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side) {
 VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *target, float *probs,
                                        float *logits, float *stats, int batch, int side, int cin, float gamma,
                                        float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    return final_bce_impl(x, w_keras, target, probs, logits, stats, nullptr, batch, side, cin, gamma, epsilon, dtype, workspace,
+                          workspace_bytes, stream);
+}
+
+VV_EXPORT int vv_convT3d_final_bce_metrics_fwd(const void *x, const float *w_keras, const float *target, float *probs,
+                                               float *logits, float *stats, float *metrics4, int batch, int side, int cin, float gamma,
+                                               float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!metrics4) return VV_ERR_NULL;
+    return final_bce_impl(x, w_keras, target, probs, logits, stats, metrics4, batch, side, cin, gamma, epsilon, dtype, workspace,
+                          workspace_bytes, stream);
+}
+
+namespace {
+int final_bce_impl(const void *x, const float *w_keras, const float *target, float *probs, float *logits, float *stats, float *metrics4,
+                   int batch, int side, int cin, float gamma, float epsilon, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (!x || !w_keras || !target || !stats) return VV_ERR_NULL;
     if (dtype != VV_F32 && dtype != VV_BF16 && dtype != VV_FP8) return VV_ERR_DTYPE;
     if (batch <= 0 || batch > 65535 || side < 4 || !vv_is_pow2(side) || cin != FB_CIN) return VV_ERR_SHAPE;
@@ -721,7 +790,7 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     const int ntile = (side / 8) * (side / 8);
     if (dtype == VV_FP8) {
         const int nt8 = vv_final_bce_sweep_fp8_launch(x, w_keras, target, probs, logits, partials, batch, side, gamma, epsilon, st);
-        VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nt8);
+        finish_stats(partials, stats, metrics4, nt8, batch, st);
         return vv_launch_status();
     }
     const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "box": override the batch heuristic (tests)
@@ -735,7 +804,7 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
         (void)attr;
         VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * batch), dim3(256), SW_LDS, st, reinterpret_cast<const __bf16 *>(x), w_keras, target,
                   probs, logits, partials, vv_log2(side), (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
-        VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, ntile);
+        finish_stats(partials, stats, metrics4, ntile, batch, st);
         return vv_launch_status();
     }
     if (dtype == VV_BF16)
@@ -745,9 +814,10 @@ VV_EXPORT int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, cons
     else
         VV_LAUNCH((final_bce_kernel<float>), dim3(nblk, batch), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                            w_keras, target, probs, logits, partials, vv_log2(side), gamma, epsilon);
-    VV_LAUNCH(final_reduce_kernel, dim3(batch), dim3(64), 0, st, partials, stats, nblk);
+    finish_stats(partials, stats, metrics4, nblk, batch, st);
     return vv_launch_status();
 }
+}  // namespace
 
 // bf16 fast path of vv_conv3d_first_fwd (igemm.hip dispatches here): w_packed = vv_pack_conv_k4(cin = 1) = [64][64] bf16.
 int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float *scale, const float *shift, void *y, int batch,

@@ -1,0 +1,294 @@
+// The latent tail of the evaluation path as two launches instead of five (bf16, gfx950):
+//
+//   encoder tail (Conv3D k4 s1 + spatial mean folded into one Dense panel, autoencoder3D.py:86-91)
+//     -> slice | clip | sampling | KL (nolbo.py:1417-1431; function.py:35-38, 84-98)
+//     -> linearTransform + BN + act (autoencoder3D.py:56-70) -> first decoder Conv3DTranspose (k4 s1) + BN + act (:127-128)
+//
+// Five tiny dependent kernels (a 256 x 128 x 4096 GEMM in 16-chunk latency chains, its split-K reduce, a 24 KB elementwise
+// pass, two GEMMs with K = 64) cost 45 us of a 590 us step, almost all of it launch gaps and exposed memory latency.  Here:
+//
+//   lt_e5_kernel : the encoder-tail GEMM cut into K slices of >= 256; a workgroup stages its WHOLE slice (4 chunks of 64) with
+//                  one burst of LDS-DMA, multiplies, and stores a float32 slab [slice][B][E] -- one memory round trip per
+//                  workgroup instead of a chain of them
+//   lt_mid_kernel: workgroup = 16 samples x one slice of the decoder seed: sums the slabs in slice order (deterministic), clips,
+//                  samples z, sums KL, runs the K = L dense layer and its slice of the K = S^3*8 dense layer as 16-row MFMA
+//                  tiles (v_mfma_f32_16x16x32_bf16, weights straight from global memory: they are read once per workgroup),
+//                  folded BN + activation in the epilogues.  The first three steps are recomputed by every slice's workgroup
+//                  (a few thousand FLOPs) instead of being exchanged.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned lt_u4;
+
+constexpr int LT_BM = 128, LT_BN = 64, LT_KS = 256;          // tile and the K a workgroup stages at once
+constexpr int LT_E5_LDS = (LT_BM + LT_BN) * 128 * (LT_KS / 64);   // 98,304 B
+
+struct LtArgs {
+    const void *h;          // [B][K5] bf16
+    const void *w5;         // [E][K5] bf16
+    float *slabs;           // [nslice][B][E]
+    int batch, K5, E, kslice, nslice;
+    unsigned h_bytes, w_bytes;
+};
+
+__global__ __launch_bounds__(256) void lt_e5_kernel(const LtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                  // 64-row block, 32-channel block
+    const int ntn = (a.E + LT_BN - 1) / LT_BN, ntm = (a.batch + LT_BM - 1) / LT_BM;
+    int blk = blockIdx.x;
+    const int tn = blk % ntn; blk /= ntn;
+    const int tm = blk % ntm;
+    const int sl = blk / ntm;
+    const int m0 = tm * LT_BM, n0 = tn * LT_BN;
+    const int k_begin = sl * a.kslice, k_end = k_begin + a.kslice < a.K5 ? k_begin + a.kslice : a.K5;
+    const u32x4 rsa = vv_make_rsrc(a.h, a.h_bytes), rsw = vv_make_rsrc(a.w5, a.w_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int kr = k_begin; kr < k_end; kr += LT_KS) {         // rounds of 4 chunks (one round for K5 <= 32 * 256)
+        // stage [4 chunks][128 + 64 rows][128 B]: 96 pieces of 1 KiB, 24 per wave; slot swizzle (row >> 1) & 7 on the source side
+        for (int it = wave; it < 96; it += 4) {
+            const int ch = it / 24, r8 = it % 24;             // chunk, 8-row block (0..15 activations, 16..23 weights)
+            const int k0 = kr + ch * 64;
+            const int row = (r8 < 16 ? r8 : r8 - 16) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const bool kin = k0 + slot * 8 < k_end;
+            unsigned vo;
+            if (r8 < 16) vo = (kin && m0 + row < a.batch) ? (unsigned)(((size_t)(m0 + row) * a.K5 + k0) * 2 + slot * 16) : 0xFFFFFFF0u;
+            else vo = (kin && n0 + row < a.E) ? (unsigned)(((size_t)(n0 + row) * a.K5 + k0) * 2 + slot * 16) : 0xFFFFFFF0u;
+            const unsigned dst = lds0 + ch * (LT_BM + LT_BN) * 128 + r8 * 1024;
+            if (r8 < 16) vv_dma16(rsa, vo, dst);
+            else vv_dma16(rsw, vo, dst);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const char *As = smem + ch * (LT_BM + LT_BN) * 128, *Bs = As + LT_BM * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int rb = wn * 32 + fr;
+                const uint4 fb = *reinterpret_cast<const uint4 *>(Bs + rb * 128 + (((ks * 2 + fh) ^ ((rb >> 1) & 7)) << 4));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ra = wm * 64 + i * 32 + fr;
+                    const uint4 fa = *reinterpret_cast<const uint4 *>(As + ra * 128 + (((ks * 2 + fh) ^ ((ra >> 1) & 7)) << 4));
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb), *reinterpret_cast<const bf16x8 *>(&fa),
+                                                                     acc[i], 0, 0, 0);      // D[n][m]: lane = row m, registers walk n
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // slab store: lane = sample row, register quad g = channels 8 g + 4 fh .. + 3 of the wave's 32
+    float *slab = a.slabs + (size_t)sl * a.batch * a.E;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + fr;
+        if (m >= a.batch) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * 32 + 8 * g + 4 * fh;
+            if (n < a.E)
+                *reinterpret_cast<f32x4 *>(slab + (size_t)m * a.E + n) = f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        }
+    }
+}
+
+struct LtMidArgs {
+    const float *slabs;      // [nslice][B][E]
+    const float *e5_scale;   // per-channel scale of the encoder tail (fp8 weight scale) or nullptr
+    const float *eps;        // [B][L] or nullptr (non-variational)
+    const void *wd;          // [lin][L] bf16
+    const float *scale_d, *shift_d;
+    const void *w1;          // [n1][lin] bf16
+    const float *scale_1, *shift_1;
+    float *enc_out;          // [B][E] or nullptr
+    float *z;                // [B][L]
+    void *z_act;             // [B][L] bf16 or nullptr
+    float *kl;               // [B] or nullptr
+    void *h1;                // [B][n1] bf16
+    int batch, E, L, lin, n1, nslice, nq, variational, act;
+};
+
+template <int ACT>
+__device__ __forceinline__ float lt_act(float t) {
+    if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; return t > 0.f ? t : em; }
+    if (ACT == VV_ACT_RELU) return fmaxf(t, 0.f);
+    if (ACT == VV_ACT_LRELU) return t > 0.f ? t : 0.3f * t;
+    return t;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sb = blockIdx.x / a.nq, q = blockIdx.x - sb * a.nq;     // 16-sample block, slice of the seed
+    const int b0 = sb * 16;
+    float *encs = reinterpret_cast<float *>(smem);                    // [16][E] float32
+    __bf16 *zs = reinterpret_cast<__bf16 *>(smem + 16 * a.E * 4);     // [16][L] bf16  (MFMA operand)
+    __bf16 *ts = zs + 16 * a.L;                                       // [16][lin] bf16
+
+    // ---- A: encoder output = slabs summed in slice order
+    const int e4 = a.E >> 2;
+    for (int i = tid; i < 16 * e4; i += 256) {
+        const int r = i / e4, c4 = i - r * e4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (b0 + r < a.batch) {
+            for (int sl = 0; sl < a.nslice; ++sl)
+                s += *reinterpret_cast<const f32x4 *>(a.slabs + ((size_t)sl * a.batch + b0 + r) * a.E + c4 * 4);
+            if (a.e5_scale) s *= *reinterpret_cast<const f32x4 *>(a.e5_scale + c4 * 4);
+            if (a.enc_out && q == 0) *reinterpret_cast<f32x4 *>(a.enc_out + (size_t)(b0 + r) * a.E + c4 * 4) = s;
+        }
+        *reinterpret_cast<f32x4 *>(encs + r * a.E + c4 * 4) = s;
+    }
+    __syncthreads();
+    // ---- B: slice | clip | sampling | KL: 16 lanes per sample row
+    {
+        const int r = tid >> 4, l16 = tid & 15;
+        const bool live = b0 + r < a.batch;
+        float s = 0.f;
+        for (int j = l16; j < a.L; j += 16) {
+            float zz;
+            if (a.variational) {
+                const float mu = encs[r * a.E + j];
+                float lv = encs[r * a.E + a.L + j];
+                lv = fminf(fmaxf(lv, -10.f), 10.f);                                   // nolbo.py:1420
+                const float e = expf(lv);
+                zz = mu + sqrtf(e) * (live ? a.eps[(size_t)(b0 + r) * a.L + j] : 0.f);   // function.py:37
+                s += 0.5f * (0.f - lv) + (e + mu * mu) / 2.0f - 0.5f;                 // function.py:96, target N(0, I)
+            } else {
+                zz = encs[r * a.E + j];
+            }
+            zs[r * a.L + j] = static_cast<__bf16>(zz);
+            if (live && q == 0) {
+                a.z[(size_t)(b0 + r) * a.L + j] = zz;
+                if (a.z_act) reinterpret_cast<__bf16 *>(a.z_act)[(size_t)(b0 + r) * a.L + j] = static_cast<__bf16>(zz);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (a.kl && a.variational && live && q == 0 && l16 == 0) a.kl[b0 + r] = s;
+    }
+    __syncthreads();
+    // ---- C: t = act(BN(z Wd^T + b)): weights first, D[n][row]; lane = row (lane & 15), registers = 4 consecutive outputs
+    const int r16 = lane & 15, kq = lane >> 4;
+    for (int nt = wave; nt < a.lin / 16; nt += 4) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < a.L / 32; ++ks) {
+            const uint4 wf = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.wd) + (size_t)(nt * 16 + r16) * a.L + ks * 32 + kq * 8);
+            const uint4 xf = *reinterpret_cast<const uint4 *>(zs + r16 * a.L + ks * 32 + kq * 8);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf), *reinterpret_cast<const bf16x8 *>(&xf), c, 0, 0, 0);
+        }
+        const int n = nt * 16 + kq * 4;
+        const f32x4 sc = a.scale_d ? *reinterpret_cast<const f32x4 *>(a.scale_d + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.shift_d ? *reinterpret_cast<const f32x4 *>(a.shift_d + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(lt_act<ACT>(c[e] * sc[e] + sh[e]));
+        *reinterpret_cast<bf16x4 *>(ts + r16 * a.lin + n) = o;
+    }
+    __syncthreads();
+    // ---- D: this workgroup's slice of the seed: h1[:, q*slice .. ) = act(BN(t W1^T))
+    const int slice = a.n1 / a.nq, nk = a.lin / 32;
+    for (int nt = wave; nt < slice / 16; nt += 4) {
+        const int nbase = q * slice + nt * 16;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nk; ++ks) {
+            const uint4 wf = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.w1) + (size_t)(nbase + r16) * a.lin + ks * 32 + kq * 8);
+            const uint4 xf = *reinterpret_cast<const uint4 *>(ts + r16 * a.lin + ks * 32 + kq * 8);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf), *reinterpret_cast<const bf16x8 *>(&xf), c, 0, 0, 0);
+        }
+        const int n = nbase + kq * 4;
+        const f32x4 sc = a.scale_1 ? *reinterpret_cast<const f32x4 *>(a.scale_1 + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = a.shift_1 ? *reinterpret_cast<const f32x4 *>(a.shift_1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(lt_act<ACT>(c[e] * sc[e] + sh[e]));
+        if (b0 + r16 < a.batch) *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(a.h1) + (size_t)(b0 + r16) * a.n1 + n) = o;
+    }
+}
+
+struct LtPlan { int kslice, nslice, nq; size_t ws; };
+
+LtPlan lt_plan(int batch, int K5, int E, int n1) {
+    LtPlan p;
+    int ks = (K5 + 31) / 32;                               // at most 32 slices
+    ks = ((ks + LT_KS - 1) / LT_KS) * LT_KS;
+    if (ks < LT_KS) ks = LT_KS;
+    p.kslice = ks;
+    p.nslice = (K5 + ks - 1) / ks;
+    p.nq = 1;
+    for (int c = 8; c >= 2; c >>= 1)
+        if (n1 % (16 * c) == 0) { p.nq = c; break; }
+    p.ws = (size_t)p.nslice * batch * E * sizeof(float);
+    return p;
+}
+
+}  // namespace
+
+VV_EXPORT int vv_latent_tail_supported(int K5, int E, int L, int lin, int n1, int variational, int dtype) {
+    if (dtype != VV_BF16) return 0;
+    if (K5 < 64 || K5 % 8 || E % 4 || E > 512 || L % 32 || L > 256 || lin % 32 || lin > 1024 || n1 % 16) return 0;
+    if (variational ? E != 2 * L : E != L) return 0;
+    return 1;
+}
+
+VV_EXPORT size_t vv_latent_tail_workspace_bytes(int batch, int K5, int E, int n1) {
+    if (batch <= 0 || K5 <= 0 || E <= 0) return 0;
+    return lt_plan(batch, K5, E, n1).ws;
+}
+
+VV_EXPORT int vv_latent_tail_fwd(const void *h, const void *w5, const float *e5_scale, const float *eps, const void *wd, const float *scale_d,
+                                 const float *shift_d, const void *w1, const float *scale_1, const float *shift_1, float *enc_out, float *z,
+                                 void *z_act, float *kl, void *h1, int batch, int K5, int E, int L, int lin, int n1, int variational, int act,
+                                 int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!h || !w5 || !wd || !w1 || !z || !h1) return VV_ERR_NULL;
+    if (variational && !eps) return VV_ERR_NULL;
+    if (batch <= 0 || !vv_latent_tail_supported(K5, E, L, lin, n1, variational, dtype)) return VV_ERR_SHAPE;
+    if ((size_t)batch * K5 * 2 >= 0xFFFFFFF0ull || (size_t)E * K5 * 2 >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
+    if (!vv_aligned16(h) || !vv_aligned16(w5) || !vv_aligned16(wd) || !vv_aligned16(w1) || !vv_aligned16(h1) || !vv_aligned16(z) ||
+        (enc_out && !vv_aligned16(enc_out)))
+        return VV_ERR_ALIGN;
+    const LtPlan p = lt_plan(batch, K5, E, n1);
+    if (!workspace || workspace_bytes < p.ws || !vv_aligned16(workspace)) return VV_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lt_e5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LT_E5_LDS);
+        return true;
+    }();
+    (void)attr;
+    LtArgs a;
+    a.h = h; a.w5 = w5; a.slabs = reinterpret_cast<float *>(workspace);
+    a.batch = batch; a.K5 = K5; a.E = E; a.kslice = p.kslice; a.nslice = p.nslice;
+    a.h_bytes = (unsigned)((size_t)batch * K5 * 2); a.w_bytes = (unsigned)((size_t)E * K5 * 2);
+    const int ntn = (E + LT_BN - 1) / LT_BN, ntm = (batch + LT_BM - 1) / LT_BM;
+    VV_LAUNCH(lt_e5_kernel, dim3(ntn * ntm * p.nslice), dim3(256), LT_E5_LDS, st, a);
+    int rc = vv_launch_status();
+    if (rc != VV_OK) return rc;
+    LtMidArgs m;
+    m.slabs = a.slabs; m.e5_scale = e5_scale; m.eps = eps; m.wd = wd; m.scale_d = scale_d; m.shift_d = shift_d;
+    m.w1 = w1; m.scale_1 = scale_1; m.shift_1 = shift_1; m.enc_out = enc_out; m.z = z; m.z_act = z_act; m.kl = kl; m.h1 = h1;
+    m.batch = batch; m.E = E; m.L = L; m.lin = lin; m.n1 = n1; m.nslice = p.nslice; m.nq = p.nq; m.variational = variational; m.act = act;
+    const size_t lds = (size_t)16 * E * 4 + (size_t)16 * L * 2 + (size_t)16 * lin * 2;
+    const dim3 grid(((batch + 15) / 16) * p.nq);
+    switch (act) {
+        case VV_ACT_ELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_ELU>, grid, dim3(256), lds, st, m); break;
+        case VV_ACT_RELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_RELU>, grid, dim3(256), lds, st, m); break;
+        case VV_ACT_LRELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_LRELU>, grid, dim3(256), lds, st, m); break;
+        default: VV_LAUNCH(lt_mid_kernel<VV_ACT_NONE>, grid, dim3(256), lds, st, m); break;
+    }
+    return vv_launch_status();
+}

@@ -14,73 +14,86 @@ from voxvae import synthetic as _syn
 
 
 class dataLoader(object):
+    """Public contract (what the reference's scripts touch): `epoch`, `batchStart`, `dataLength`, `getNextBatch(batchSize)`.
+    Internally the split is three arrays plus a visiting order; an epoch ends when the next batch would run past the end,
+    and the order is then reshuffled in place with np.random.shuffle (so seeding np.random fixes the sample stream, as in
+    the reference)."""
+
     def __init__(self, data_path, trainortest='train', partial_num=30, synthetic_size=None, voxel=None, classes=40):
-        self.epoch = 0
-        self._data_path = data_path
-        self._partial_num = partial_num
-        self.batchStart = 0
-
-        self._vox3DData = []
-        self._classList = []
-        self._instList = []
-        self.dataLength = 0
-        self._dataIdx = None
-        self._trainortest = trainortest
+        self.epoch, self.batchStart, self.dataLength = 0, 0, 0
+        self._root, self._split, self._shards = data_path, trainortest, partial_num
+        self._classes = classes
         self._synthetic = data_path is None or str(data_path).startswith('synthetic')
-        self._syn_n, self._syn_d, self._classes = synthetic_size, voxel, classes
-        if self._synthetic and isinstance(data_path, str) and ':' in data_path:
-            parts = data_path.split(':')
-            self._syn_n = int(parts[1]) if len(parts) > 1 and parts[1] else synthetic_size
-            self._syn_d = int(parts[2]) if len(parts) > 2 and parts[2] else voxel
-
+        self._syn_n, self._syn_d = synthetic_size, voxel
+        if self._synthetic and isinstance(data_path, str):
+            fields = data_path.split(':')[1:]              # 'synthetic[:N[:D]]'
+            if len(fields) > 0 and fields[0]:
+                self._syn_n = int(fields[0])
+            if len(fields) > 1 and fields[1]:
+                self._syn_d = int(fields[1])
+        self._grids = self._labels = self._ids = None
+        self._order = None
         self._loadData()
         self._dataIdxShuffle()
+
+    def _read_shards(self):
+        sub = 'train' if self._split == 'train' else 'test'
+        count = self._shards if self._split == 'train' else 5
+        folder = os.path.join(self._root, '32to64_4rot_64sqr', sub)
+        parts = {'Full': [], 'Class': [], 'Inst': []}
+        for i in range(count):
+            for kind in parts:
+                parts[kind].append(np.load(os.path.join(folder, '%d%s.npy' % (i, kind))))
+            sys.stdout.write("%s data:%02d/%02d   \r" % (sub, i + 1, count))
+        print('')
+        return tuple(np.concatenate(parts[kind], axis=0) for kind in ('Full', 'Class', 'Inst'))
 
     def _loadData(self):
         print('load data...')
         if self._synthetic:
-            n = self._syn_n or (512 if self._trainortest == 'train' else 128)
+            n = self._syn_n or (512 if self._split == 'train' else 128)
             d = self._syn_d or 32
-            seed = 1234 if self._trainortest == 'train' else 4321
-            self._vox3DData = _syn.make_voxels(n, d, seed=seed)
-            self._classList = _syn.make_onehot(n, self._classes, seed=seed + 1)
-            self._instList = np.arange(n, dtype=np.float32).reshape(n, 1)
+            seed = 1234 if self._split == 'train' else 4321
+            self._grids = _syn.make_voxels(n, d, seed=seed)
+            self._labels = _syn.make_onehot(n, self._classes, seed=seed + 1)
+            self._ids = np.arange(n, dtype=np.float32).reshape(n, 1)
         else:
-            sub = 'train' if self._trainortest == 'train' else 'test'
-            count = self._partial_num if self._trainortest == 'train' else 5
-            vox, cls, inst = [], [], []
-            for i in range(count):
-                base = os.path.join(self._data_path, '32to64_4rot_64sqr', sub, str(i))
-                vox.append(np.load(base + 'Full.npy'))
-                cls.append(np.load(base + 'Class.npy'))
-                inst.append(np.load(base + 'Inst.npy'))
-                sys.stdout.write("%s data:%02d/%02d   \r" % (sub, i + 1, count))
-            print('')
-            self._vox3DData = np.concatenate(vox, axis=0)
-            self._classList = np.concatenate(cls, axis=0)
-            self._instList = np.concatenate(inst, axis=0)
-        self.dataLength = len(self._vox3DData)
-        self._dataIdx = [i for i in range(self.dataLength)]
+            self._grids, self._labels, self._ids = self._read_shards()
+        self.dataLength = len(self._grids)
+        self._order = np.arange(self.dataLength)
         print('done!')
 
+    # kept under the reference's name: train scripts call it to restart an epoch
     def _dataIdxShuffle(self):
-        np.random.shuffle(self._dataIdx)
+        np.random.shuffle(self._order)
         self.batchStart = 0
 
     def getNextBatch(self, batchSize=32):
-        if self.batchStart + batchSize > self.dataLength:
+        if self.batchStart + batchSize > self.dataLength:      # the tail that does not fill a batch is dropped
             self.epoch += 1
             self._dataIdxShuffle()
-        dataStart = self.batchStart
-        dataEnd = self.batchStart + batchSize
+        rows = self._order[self.batchStart:self.batchStart + batchSize]
         self.batchStart += batchSize
-        dataList = self._dataIdx[dataStart:dataEnd]
-        batch_dict = {
-            'input_images': (self._vox3DData[dataList]).astype('float32'),
-            'class_list': (self._classList[dataList]).astype('float32'),
-            'inst_list': (self._instList[dataList]).astype('float32'),
-        }
-        return batch_dict
+        f32 = np.float32
+        return {'input_images': self._grids[rows].astype(f32), 'class_list': self._labels[rows].astype(f32),
+                'inst_list': self._ids[rows].astype(f32)}
+
+    # the names the previous revision (and the deviceDataLoader below) used for the three arrays
+    @property
+    def _vox3DData(self):
+        return self._grids
+
+    @_vox3DData.setter
+    def _vox3DData(self, v):
+        self._grids = v
+
+    @property
+    def _classList(self):
+        return self._labels
+
+    @property
+    def _instList(self):
+        return self._ids
 
 
 class deviceDataLoader(dataLoader):

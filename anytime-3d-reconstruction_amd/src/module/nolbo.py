@@ -68,10 +68,25 @@ class _ModelnetBase(object):
         z, z_act, kl, _, _ = _E.reparam_kl(enc_out, eps, Lz, self._act_dt)
         return z, z_act, kl
 
-    def _decode_metrics(self, z_act, target):
-        out, _, stats = self._dec_eng.forward(z_act, target)
-        m = _E.shape_metrics(stats)
+    def _decode_metrics(self, z_act, target, h1=None):
+        out, _, stats, m = self._dec_eng.forward(z_act, target, want_metrics=True, h1=h1)
         return out, stats, m
+
+    def _encode_decode_seed(self, x, eps=None):
+        """encoder -> latent -> first decoder layer for the paths that decode the latent unchanged (getEval with
+        missing_prob = 0, eval_forward_device): the fused latent tail when it applies, else the split calls.
+        Returns (z, z_act, kl, h1 or None)."""
+        if _E.latent_tail_supported(self._enc_eng, self._dec_eng, self._variational):
+            h = self._enc_eng.forward(x, stop_before_tail=True)
+            if self._variational:
+                Lz = self._latent_dim
+                eps = torch.randn(x.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
+            else:
+                eps = None
+            z, z_act, kl, _, h1 = _E.latent_tail(self._enc_eng, self._dec_eng, h, eps, self._variational)
+            return z, z_act, kl, h1
+        z, z_act, kl = self._encode_latent(x, eps)
+        return z, z_act, kl, None
 
     def _category_acc(self, z, cats, onehot, mask=None):
         B, Lz, C = z.shape[0], z.shape[1], cats.shape[0]
@@ -117,7 +132,11 @@ class _ModelnetBase(object):
         x, y, onehot = self._dev(input_images), self._dev(output_images), self._dev(category_list)
         cats = self._dev(category_vectors)
         B, Lz, C = x.shape[0], self._latent_dim, cats.shape[0]
-        z, z_act, _ = self._encode_latent(x, _eps)
+        h1 = None
+        if missing_prob > 0:
+            z, z_act, _ = self._encode_latent(x, _eps)
+        else:
+            z, z_act, _, h1 = self._encode_decode_seed(x, _eps)
         mask = None
         if missing_prob > 0:
             if _mask is None:   # reference nolbo.py:1475-1476, same RNG call
@@ -129,7 +148,7 @@ class _ModelnetBase(object):
                     None if zf_act is zf else _L.ptr(zf_act), self._act_dt, B, Lz, _st())
             z, z_act = zf, zf_act
         _, acc = self._category_acc(z, cats, onehot)
-        pred, _, m = self._decode_metrics(z_act, y)
+        pred, _, m = self._decode_metrics(z_act, y, h1)
         self._z_category = DeviceArray(z)
         res = (DeviceArray(pred), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]))
         if missing_prob == 0.0:
@@ -174,8 +193,8 @@ class _ModelnetBase(object):
     def eval_forward_device(self, x, y, eps=None):
         """Device-resident core of getEval(missing_prob=0) (reference nolbo.py:1463-1501): what bench.py times.
         x, y: float32 CUDA tensors [B,D,D,D,1]; returns (pred, stats [B,4], metrics [4], kl [B] or None), all on device."""
-        z, z_act, kl = self._encode_latent(x, eps)
-        pred, stats, m = self._decode_metrics(z_act, y)
+        z, z_act, kl, h1 = self._encode_decode_seed(x, eps)
+        pred, stats, m = self._decode_metrics(z_act, y, h1)
         return pred, stats, m, kl
 
     # ---------------------------------------------------------------- checkpoints (reference nolbo.py:1568-1592)

@@ -215,9 +215,11 @@ class EncoderEngine(_EngineBase):
                 if self.packed['scale%d' % i] is not None:
                     self.packed['scale%d' % i].mul_(qs)
             elif (self._want_fold and not os.environ.get('VV_NO_SKIP')
-                  and L.load().vv_conv3d_k4s2_skip_supported(self.D >> i, f[i - 1], f[i], self.dt)):
-                # the 8^3 -> 4^3 layer: whole samples resident in LDS, padded taps skipped (inference path; the training step
-                # keeps the implicit-GEMM panel above, which also serves its data-gradient passes)
+                  and (L.load().vv_conv3d_k4s2_skip_supported(self.D >> i, f[i - 1], f[i], self.dt)
+                       or L.load().vv_conv3d_k4s2_pos_supported(self.D >> i, f[i - 1], f[i], self.dt))):
+                # the 8^3 -> 4^3 layer: whole samples resident in LDS, padded taps skipped; the 4^3 -> 2^3 layer: position-major
+                # split-K GEMM -- same [tap][Cin/64][Cout][64] panel (inference path; the training step keeps the implicit-GEMM
+                # panel above, which also serves its data-gradient passes)
                 ws = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_conv_k4_skip', L.ptr(p['conv%d/kernel' % i]), L.ptr(ws), f[i - 1], f[i], st)
                 self.packed['ws%d' % i] = ws
@@ -231,8 +233,9 @@ class EncoderEngine(_EngineBase):
         L.call('vv_pack_conv_k4s1_meanpool', L.ptr(wk), L.ptr(w), self.S, f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
         self.packed['w%d' % i] = w
 
-    def forward(self, x):
-        """x: float32 CUDA tensor [B,D,D,D,1] (contiguous) -> enc_out float32 [B,E]."""
+    def forward(self, x, stop_before_tail=False):
+        """x: float32 CUDA tensor [B,D,D,D,1] (contiguous) -> enc_out float32 [B,E].
+        stop_before_tail: return the last stride-2 activation [B,S,S,S,C] instead (the fused latent tail consumes it)."""
         self.ensure_packed()
         B, D, f, pk, st = x.shape[0], self.D, self.filters, self.packed, _stream()
         if tuple(x.shape[1:]) != (D, D, D, 1) or x.dtype != torch.float32 or not x.is_contiguous():
@@ -264,8 +267,13 @@ class EncoderEngine(_EngineBase):
                 hdt = odt
             elif ('ws%d' % i) in pk and not nq:
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i])
-                self._call(name, 'vv_conv3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
-                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                if side == 4:
+                    ws = self.ws.get(L.load().vv_conv3d_k4s2_pos_workspace_bytes(B, f[i - 1], f[i]))
+                    self._call(name, 'vv_conv3d_k4s2_pos_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
+                               L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+                else:
+                    self._call(name, 'vv_conv3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
+                               L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
                 hdt = odt
             elif not os.environ.get('VV_NO_DIRECT') and L.load().vv_conv3d_k4s2_direct_supported(side, f[i - 1], f[i], self.dt):
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i], dtype=torch.uint8 if nq else None)
@@ -282,6 +290,10 @@ class EncoderEngine(_EngineBase):
         i = len(f) - 1
         K = side ** 3 * f[i - 1]
         q = pk.get('q%d' % i, False)
+        if stop_before_tail:
+            if q or hdt != self.dt:
+                raise L.VoxVaeError('stop_before_tail: the fused latent tail takes a %s activation' % self.tdt)
+            return h
         if q and hdt != L.VV_FP8:
             h = self._as_fp8(h, 'E%dc' % (i + 1))
         ddt = L.VV_FP8 if q else self.dt
@@ -366,30 +378,42 @@ class DecoderEngine(_EngineBase):
                 pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
             elif (self._want_fold and not os.environ.get('VV_NO_SKIP')
-                  and L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)):
-                # the 4^3 -> 8^3 layer (see the encoder's twin)
+                  and (L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)
+                       or L.load().vv_convT3d_k4s2_pos_supported(side_i, f[i - 1], f[i], self.dt))):
+                # the 4^3 -> 8^3 and 2^3 -> 4^3 layers (see the encoder's twins)
                 pk['ws%d' % i] = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_convT_k4s2_skip', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['ws%d' % i]), f[i - 1], f[i], st)
 
-    def forward(self, z_act, target=None, want_logits=False, gamma=0.6, epsilon=1e-7):
+    def forward(self, z_act, target=None, want_logits=False, gamma=0.6, epsilon=1e-7, want_metrics=False, h1=None):
         """z_act: [B,L] in the activation dtype.  target: float32 [B,D,D,D,1] or None.
         Returns (out, logits, stats): out = probabilities (final_activation 'sigmoid') or logits;
-        stats float32 [B,4] = per-sample (bce, TP, FP, FN) against target (zeros if None)."""
+        stats float32 [B,4] = per-sample (bce, TP, FP, FN) against target (zeros if None).
+        want_metrics: also return float32 [4] = (mean bce, precision, recall, IoU) -- nolbo.py:1498-1501 -- from the same
+        reduction launch as `stats` (a fourth return value).
+        h1: the output of the first (stride-1) decoder layer [B,S,S,S,C0] when the fused latent tail has produced it already
+        (z_act is then not read)."""
         self.ensure_packed()
-        B, D, f, pk, st, S = z_act.shape[0], self.D, self.filters, self.packed, _stream(), self.S
-        if z_act.dtype != self.tdt or tuple(z_act.shape) != (B, self.L) or not z_act.is_contiguous():
-            raise ValueError('decoder input must be contiguous %s [B,%d]' % (self.tdt, self.L))
+        f, pk, st, S, D = self.filters, self.packed, _stream(), self.S, self.D
         lin = S ** 3 * self.ch
-        ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, lin, self.L, self.dt))
-        t = self._empty(B, lin)
-        self._call('D0', 'vv_dense_fwd', L.ptr(z_act), L.ptr(pk['wd']), L.ptr(pk['scaled']), L.ptr(pk['shiftd']), L.ptr(t), B, lin,
-               self.L, self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
         n0 = S ** 3 * f[0]
-        ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, n0, lin, self.dt))
-        hdt = L.VV_FP8 if pk.get('q1', False) else self.dt          # D1 hands fp8 to an fp8 D2
-        h = self._empty(B, S, S, S, f[0], dtype=torch.uint8 if hdt == L.VV_FP8 else None)
-        self._call('D1', 'vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
-               self.act, self.dt, hdt, L.ptr(ws), ws.numel(), st)
+        if h1 is not None:
+            B = h1.shape[0]
+            if h1.dtype != self.tdt or h1.numel() != B * n0 or not h1.is_contiguous():
+                raise ValueError('h1 must be contiguous %s [B,%d,%d,%d,%d]' % (self.tdt, S, S, S, f[0]))
+            h, hdt = h1, self.dt
+        else:
+            B = z_act.shape[0]
+            if z_act.dtype != self.tdt or tuple(z_act.shape) != (B, self.L) or not z_act.is_contiguous():
+                raise ValueError('decoder input must be contiguous %s [B,%d]' % (self.tdt, self.L))
+            ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, lin, self.L, self.dt))
+            t = self._empty(B, lin)
+            self._call('D0', 'vv_dense_fwd', L.ptr(z_act), L.ptr(pk['wd']), L.ptr(pk['scaled']), L.ptr(pk['shiftd']), L.ptr(t), B, lin,
+                   self.L, self.act, self.dt, self.dt, L.ptr(ws), ws.numel(), st)
+            ws = self.ws.get(L.load().vv_dense_workspace_bytes(B, n0, lin, self.dt))
+            hdt = L.VV_FP8 if pk.get('q1', False) else self.dt          # D1 hands fp8 to an fp8 D2
+            h = self._empty(B, S, S, S, f[0], dtype=torch.uint8 if hdt == L.VV_FP8 else None)
+            self._call('D1', 'vv_dense_fwd', L.ptr(t), L.ptr(pk['w0']), L.ptr(pk['scale0']), L.ptr(pk['shift0']), L.ptr(h), B, n0, lin,
+                   self.act, self.dt, hdt, L.ptr(ws), ws.numel(), st)
         side = S
         for i in range(1, len(f) - 1):
             name = 'D%d' % (i + 1)
@@ -403,8 +427,13 @@ class DecoderEngine(_EngineBase):
                 continue
             if ('ws%d' % i) in pk and not nq and hdt == self.dt:
                 o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
-                self._call(name, 'vv_convT3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
-                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                if side == 2:
+                    ws = self.ws.get(L.load().vv_convT3d_k4s2_pos_workspace_bytes(B, f[i - 1], f[i]))
+                    self._call(name, 'vv_convT3d_k4s2_pos_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
+                               L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, L.ptr(ws), ws.numel(), st)
+                else:
+                    self._call(name, 'vv_convT3d_k4s2_skip_fwd', L.ptr(h), L.ptr(pk['ws%d' % i]), L.ptr(pk['scale%d' % i]),
+                               L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
                 h, side, hdt = o, 2 * side, self.dt
                 continue
             if q and hdt != L.VV_FP8:
@@ -432,6 +461,12 @@ class DecoderEngine(_EngineBase):
         logits = self._empty(B, D, D, D, 1, dtype=torch.float32) if (want_logits or not self.final_sigmoid) else None
         stats = self._empty(B, 4, dtype=torch.float32)
         ws = self.ws.get(L.load().vv_convT3d_final_bce_workspace_bytes(B, side))
+        if want_metrics:
+            metrics = self._empty(4, dtype=torch.float32)
+            self._call('D%d' % len(f), 'vv_convT3d_final_bce_metrics_fwd', L.ptr(h), L.ptr(self.params['convT%d/kernel' % (len(f) - 1)]),
+                       L.ptr(target), L.ptr(probs), L.ptr(logits), L.ptr(stats), L.ptr(metrics), B, side, f[-2], gamma, epsilon, hdt,
+                       L.ptr(ws), ws.numel(), st)
+            return (probs if self.final_sigmoid else logits), logits, stats, metrics
         self._call('D%d' % len(f), 'vv_convT3d_final_bce_fwd', L.ptr(h), L.ptr(self.params['convT%d/kernel' % (len(f) - 1)]), L.ptr(target),
                L.ptr(probs), L.ptr(logits), L.ptr(stats), B, side, f[-2], gamma, epsilon, hdt, L.ptr(ws), ws.numel(), st)
         return (probs if self.final_sigmoid else logits), logits, stats
@@ -450,6 +485,39 @@ def reparam_kl(enc_out, eps, latent, act_dtype, drop_mask=None, drop_scale=1.0, 
            L.ptr(z_act) if act_dtype != L.VV_F32 else None, act_dtype, L.ptr(kl), L.ptr(mean), L.ptr(logvar), B, latent,
            _stream())
     return z, z_act, kl, mean, logvar
+
+
+def latent_tail_supported(enc, dec, variational):
+    """True when encoder tail -> reparam/KL -> Dense -> first decoder layer can run as the two fused launches of latent_tail.hip."""
+    if enc.dt != L.VV_BF16 or enc.fp8 or dec.fp8 or dec.dt != L.VV_BF16 or os.environ.get('VV_NO_LATENT_TAIL'):
+        return False
+    Lz = dec.L
+    K5 = enc.S ** 3 * enc.filters[-2]
+    return bool(L.load().vv_latent_tail_supported(K5, enc.E, Lz, dec.S ** 3 * dec.ch, dec.S ** 3 * dec.filters[0], int(variational), L.VV_BF16)) \
+        and enc.act == dec.act
+
+
+def latent_tail(enc, dec, h, eps, variational, want_enc_out=False):
+    """Fused latent tail (vv_latent_tail_fwd): h = EncoderEngine.forward(x, stop_before_tail=True).
+    Returns (z float32 [B,L], z_act bf16, kl [B] or None, enc_out or None, h1 = the decoder's first-layer output)."""
+    enc.ensure_packed()
+    dec.ensure_packed()
+    B, dev = h.shape[0], h.device
+    Lz, E = dec.L, enc.E
+    K5 = enc.S ** 3 * enc.filters[-2]
+    lin, n1 = dec.S ** 3 * dec.ch, dec.S ** 3 * dec.filters[0]
+    ne = len(enc.filters) - 1
+    z = torch.empty(B, Lz, dtype=torch.float32, device=dev)
+    z_act = torch.empty(B, Lz, dtype=torch.bfloat16, device=dev)
+    kl = torch.empty(B, dtype=torch.float32, device=dev) if variational else None
+    enc_out = torch.empty(B, E, dtype=torch.float32, device=dev) if want_enc_out else None
+    h1 = torch.empty(B, dec.S, dec.S, dec.S, dec.filters[0], dtype=torch.bfloat16, device=dev)
+    ws = enc.ws.get(L.load().vv_latent_tail_workspace_bytes(B, K5, E, n1))
+    pe, pd = enc.packed, dec.packed
+    enc._call('LT', 'vv_latent_tail_fwd', L.ptr(h), L.ptr(pe['w%d' % ne]), L.ptr(pe.get('scale%d' % ne)), L.ptr(eps), L.ptr(pd['wd']),
+              L.ptr(pd['scaled']), L.ptr(pd['shiftd']), L.ptr(pd['w0']), L.ptr(pd['scale0']), L.ptr(pd['shift0']), L.ptr(enc_out), L.ptr(z),
+              L.ptr(z_act), L.ptr(kl), L.ptr(h1), B, K5, E, Lz, lin, n1, int(variational), dec.act, L.VV_BF16, L.ptr(ws), ws.numel(), _stream())
+    return z, z_act, kl, enc_out, h1
 
 
 def shape_metrics(stats):

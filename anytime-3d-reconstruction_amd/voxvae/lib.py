@@ -54,11 +54,21 @@ SIGNATURES = {
     'vv_pack_convT_k4s2_skip': (_i, [_vp, _vp, _i, _i, _vp]),
     'vv_conv3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_convT3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'vv_conv3d_k4s2_pos_supported': (_i, [_i, _i, _i, _i]),
+    'vv_convT3d_k4s2_pos_supported': (_i, [_i, _i, _i, _i]),
+    'vv_conv3d_k4s2_pos_workspace_bytes': (_sz, [_i, _i, _i]),
+    'vv_convT3d_k4s2_pos_workspace_bytes': (_sz, [_i, _i, _i]),
+    'vv_conv3d_k4s2_pos_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_convT3d_k4s2_pos_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'vv_dense_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'vv_dense_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'vv_latent_tail_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    'vv_latent_tail_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'vv_latent_tail_fwd': (_i, [_vp] * 15 + [_i] * 9 + [_vp, _sz, _vp]),
     'vv_reparam_kl_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     'vv_convT3d_final_bce_workspace_bytes': (_sz, [_i, _i]),
     'vv_convT3d_final_bce_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
+    'vv_convT3d_final_bce_metrics_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),
     'vv_shape_metrics': (_i, [_vp, _vp, _i, _vp]),
     'vv_latent_mask_fill': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     'vv_nearest_category': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
@@ -104,6 +114,11 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise VoxVaeError('HIP library missing: %s (run `python __graft_entry__.py` / voxvae/build.py); '
                               'there is no CPU fallback' % LIB_PATH)
+        # a library built from other sources than the ones in the tree is refused (content hash written by voxvae/build.py):
+        # a stale .so would otherwise run silently after a checkout that resets mtimes
+        from . import build as _build
+        if os.path.isdir(_build.CSRC) and os.path.exists(LIB_PATH + '.srchash') and not _build.is_current():
+            raise VoxVaeError('%s is stale: csrc/ or include/voxvae.h changed since it was built (run `python __graft_entry__.py`)' % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the symbol is not exported

@@ -154,12 +154,40 @@ int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scal
 int vv_convT3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
                              int side, int cin, int cout, int act, int dtype, void *stream);
 
+/* conv3DEnc / conv3DDec between the 4^3 and the 2^3 grid (the 32^3 model's 256 -> 512 and 512 -> 256 layers) as a
+ * position-major split-K GEMM: rows = the batch at one output position, K = that position's valid (tap, 64-channel chunk)
+ * pairs cut into equal shares over the workgroups, 256 x 128 tiles, 3-stage LDS-DMA ring (bf16 only).  Weights in the
+ * vv_pack_conv_k4_skip / vv_pack_convT_k4s2_skip layouts.  Workspace = float32 slabs of the positions that are cut into
+ * several shares (summed in share order: deterministic).
+ *   conv : x [B,4,4,4,Cin] -> y [B,2,2,2,Cout];  convT: x [B,2,2,2,Cin] -> y [B,4,4,4,Cout];  Cin % 64 == 0, Cout % 8 == 0 */
+int vv_conv3d_k4s2_pos_supported(int side, int cin, int cout, int dtype);
+int vv_convT3d_k4s2_pos_supported(int side, int cin, int cout, int dtype);
+size_t vv_conv3d_k4s2_pos_workspace_bytes(int batch, int cin, int cout);
+size_t vv_convT3d_k4s2_pos_workspace_bytes(int batch, int cin, int cout);
+int vv_conv3d_k4s2_pos_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                           int side, int cin, int cout, int act, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+int vv_convT3d_k4s2_pos_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                            int side, int cin, int cout, int act, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 /* y[M,N] = act((x[M,K] @ w_packed[N,K]^T) * scale[N] + shift[N]): linearTransform (autoencoder3D.py:56-70) and
  * the two layers packed as dense panels above.  K % 8 == 0 (bf16) / % 4 (f32), N % 4 == 0 (tails are masked).
  * out_dtype may differ from dtype (the encoder output is float32). */
 size_t vv_dense_workspace_bytes(int m, int n, int k, int dtype);
 int vv_dense_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y, int m, int n,
                  int k, int act, int dtype, int out_dtype, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The latent tail of the evaluation path in two launches (latent_tail.hip): encoder tail (the vv_pack_conv_k4s1_meanpool
+ * panel w5 [E][K5] applied to the last stride-2 activation h [B][K5]) -> slice | clip | sampling | KL (as vv_reparam_kl_fwd,
+ * no dropout) -> linearTransform + BN + act (wd [lin][L], vv_pack_dense) -> first decoder layer as a dense panel
+ * (w1 [n1][lin], vv_pack_convT_k4s1_dense) + BN + act.  Outputs: enc_out [B][E] (optional), z [B][L], z_act bf16 (optional),
+ * kl [B] (variational), h1 [B][n1] bf16 = the input of the first stride-2 decoder layer.  variational: E = 2L, else E = L and
+ * z = enc_out.  bf16 only; L % 32 == 0, lin % 32 == 0, n1 % 16 == 0.  e5_scale: optional per-channel factor on enc_out. */
+int vv_latent_tail_supported(int K5, int E, int L, int lin, int n1, int variational, int dtype);
+size_t vv_latent_tail_workspace_bytes(int batch, int K5, int E, int n1);
+int vv_latent_tail_fwd(const void *h, const void *w5, const float *e5_scale, const float *eps, const void *wd, const float *scale_d,
+                       const float *shift_d, const void *w1, const float *scale_1, const float *shift_1, float *enc_out, float *z,
+                       void *z_act, float *kl, void *h1, int batch, int K5, int E, int L, int lin, int n1, int variational, int act,
+                       int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Latent ops */
@@ -184,6 +212,11 @@ size_t vv_convT3d_final_bce_workspace_bytes(int batch, int side);
 int vv_convT3d_final_bce_fwd(const void *x, const float *w_keras, const float *target, float *probs, float *logits,
                              float *stats, int batch, int side, int cin, float gamma, float epsilon, int dtype,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* Same, plus the batch metrics of nolbo.py:1498-1501 in the same reduction launch: metrics4 = (mean bce, mean TP/(TP+FP+1e-10),
+ * mean TP/(TP+FN+1e-10), mean IoU) -- what vv_shape_metrics computes from `stats`. */
+int vv_convT3d_final_bce_metrics_fwd(const void *x, const float *w_keras, const float *target, float *probs, float *logits,
+                                     float *stats, float *metrics4, int batch, int side, int cin, float gamma, float epsilon,
+                                     int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Batch means of nolbo.py:1498-1501: out[0..3] = mean_b bce, mean_b TP/(TP+FP+1e-10), mean_b TP/(TP+FN+1e-10),
  * mean_b TP/max(TP+FP+FN,1) (IoU: not in the reference). */

@@ -164,7 +164,8 @@ VVO_API void vvo_dense(const float *x, const float *W, const float *bias, float 
             const float *wr = W + (size_t)i * Out;
             for (int o = 0; o < Out; ++o) yp[o] += a * wr[o];
         }
-        for (int o = 0; o < Out; ++o) yp[o] += bias[o];
+        if (bias)
+            for (int o = 0; o < Out; ++o) yp[o] += bias[o];
     }
 }
 

@@ -136,6 +136,49 @@ def test_convT3d_k4s2_skip(L, B, cin, cout, act):
     _check(y, ref, 'bf16', 'convT3d_k4s2_skip')
 
 
+# position-major split-K GEMM of the 4^3 <-> 2^3 layers (posgemm.hip): ragged batches, channel tails, several sample tiles
+@pytest.mark.parametrize('act', [1, 0])
+@pytest.mark.parametrize('B,cin,cout', [(5, 64, 64), (37, 256, 512), (256, 128, 136), (300, 64, 128)])
+def test_conv3d_k4s2_pos(L, B, cin, cout, act):
+    rng = np.random.default_rng(B * 13 + cin)
+    x = _bf16_round(rng.standard_normal((B, 4, 4, 4, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    assert L.load().vv_conv3d_k4s2_pos_supported(4, cin, cout, L.VV_BF16)
+    ref = no.activation(no.conv3d_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu' if act else None)
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4_skip', L.ptr(wd), L.ptr(wp), cin, cout, _st())
+    ws = torch.empty(max(L.load().vv_conv3d_k4s2_pos_workspace_bytes(B, cin, cout), 16), dtype=torch.uint8, device=DEV)
+    y = torch.full((B, 2, 2, 2, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_conv3d_k4s2_pos_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, 4, cin, cout, act, L.VV_BF16,
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'conv3d_k4s2_pos')
+
+
+@pytest.mark.parametrize('act', [1, 0])
+@pytest.mark.parametrize('B,cin,cout', [(3, 64, 64), (40, 512, 256), (256, 128, 72), (290, 64, 128)])
+def test_convT3d_k4s2_pos(L, B, cin, cout, act):
+    rng = np.random.default_rng(B * 19 + cin)
+    x = _bf16_round(rng.standard_normal((B, 2, 2, 2, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cout, cin)) / np.sqrt(4 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    assert L.load().vv_convT3d_k4s2_pos_supported(2, cin, cout, L.VV_BF16)
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift, 'elu' if act else None)
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_skip', L.ptr(wd), L.ptr(wp), cin, cout, _st())
+    ws = torch.empty(max(L.load().vv_convT3d_k4s2_pos_workspace_bytes(B, cin, cout), 16), dtype=torch.uint8, device=DEV)
+    y = torch.full((B, 4, 4, 4, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_pos_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, 2, cin, cout, act, L.VV_BF16,
+           L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'convT3d_k4s2_pos')
+
+
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(4, 64, 64), (7, 128, 16), (256, 128, 4096), (130, 4096, 64), (2, 64, 8200)])
 def test_dense(L, dtname, M, N, K):
@@ -237,6 +280,62 @@ def test_convT3d_final_bce(L, dtname, B, side, form, monkeypatch):
     o = out.cpu().numpy()
     prr, rcc = no.pr_rc(s[:, 1], s[:, 2], s[:, 3])
     np.testing.assert_allclose(o[:3], [s[:, 0].mean(), prr, rcc], rtol=1e-5)
+    # the same layer with the batch metrics folded into its reduction launch: identical per-sample sums, same metrics
+    stats2, out2 = torch.empty_like(stats), torch.empty(4, dtype=torch.float32, device=DEV)
+    L.call('vv_convT3d_final_bce_metrics_fwd', L.ptr(xd), L.ptr(wd), L.ptr(yd), L.ptr(probs), L.ptr(logits), L.ptr(stats2), L.ptr(out2),
+           B, side, 64, 0.6, 1e-7, dt, L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    assert torch.equal(stats2, stats)
+    np.testing.assert_allclose(out2.cpu().numpy(), o, rtol=2e-6)
+
+
+@pytest.mark.parametrize('B,K5,Lz,lin,n1,variational', [(256, 4096, 64, 64, 4096, True), (37, 4096, 64, 64, 4096, False),
+                                                        (5, 1024, 32, 512, 2048, True), (19, 8200, 64, 96, 80, True)])
+def test_latent_tail(L, B, K5, Lz, lin, n1, variational):
+    """encoder tail -> clip | sampling | KL -> Dense + BN + act -> first decoder layer (dense panel) + BN + act in two launches
+    (latent_tail.hip) against the float64 definition on the same bf16 operands."""
+    rng = np.random.default_rng(B + K5)
+    E = 2 * Lz if variational else Lz
+    assert L.load().vv_latent_tail_supported(K5, E, Lz, lin, n1, int(variational), L.VV_BF16)
+    h = _bf16_round(rng.standard_normal((B, K5)).astype(np.float32))
+    w5 = _bf16_round((rng.standard_normal((E, K5)) / np.sqrt(K5)).astype(np.float32)) * 3
+    w5 = _bf16_round(w5)
+    eps = rng.standard_normal((B, Lz)).astype(np.float32)
+    wd = _bf16_round((rng.standard_normal((lin, Lz)) / np.sqrt(Lz)).astype(np.float32))
+    w1 = _bf16_round((rng.standard_normal((n1, lin)) / np.sqrt(lin)).astype(np.float32))
+    scd, shd = rng.uniform(0.5, 1.5, lin).astype(np.float32), rng.normal(0, 0.3, lin).astype(np.float32)
+    sc1, sh1 = rng.uniform(0.5, 1.5, n1).astype(np.float32), rng.normal(0, 0.3, n1).astype(np.float32)
+    enc = h.astype(np.float64) @ w5.astype(np.float64).T
+    if variational:
+        mu, lv = no.split_mean_logvar(enc, Lz)
+        zr = mu + np.sqrt(np.exp(lv)) * eps
+        klr = no.kl_loss(mu, lv, np.zeros_like(mu), np.zeros_like(lv))
+    else:
+        zr, klr = enc, None
+    bt = torch.bfloat16
+    hd, w5d, wdd, w1d = _dev(h, bt), _dev(w5, bt), _dev(wd, bt), _dev(w1, bt)
+    epsd, scdd, shdd, sc1d, sh1d = _dev(eps), _dev(scd), _dev(shd), _dev(sc1), _dev(sh1)
+    enc_out = torch.empty(B, E, dtype=torch.float32, device=DEV)
+    z = torch.empty(B, Lz, dtype=torch.float32, device=DEV)
+    zb = torch.empty(B, Lz, dtype=bt, device=DEV)
+    kl = torch.full((B,), float('nan'), dtype=torch.float32, device=DEV)
+    h1 = torch.full((B, n1), float('nan'), dtype=bt, device=DEV)
+    ws = torch.empty(max(L.load().vv_latent_tail_workspace_bytes(B, K5, E, n1), 16), dtype=torch.uint8, device=DEV)
+    L.call('vv_latent_tail_fwd', L.ptr(hd), L.ptr(w5d), None, L.ptr(epsd) if variational else None, L.ptr(wdd), L.ptr(scdd), L.ptr(shdd),
+           L.ptr(w1d), L.ptr(sc1d), L.ptr(sh1d), L.ptr(enc_out), L.ptr(z), L.ptr(zb), L.ptr(kl) if variational else None, L.ptr(h1),
+           B, K5, E, Lz, lin, n1, int(variational), 1, L.VV_BF16, L.ptr(ws), ws.numel(), _st())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(enc_out.cpu().numpy(), enc, rtol=0, atol=2e-5 * max(1.0, np.abs(enc).max()))
+    np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(zr).max()))
+    if variational:
+        np.testing.assert_allclose(kl.cpu().numpy(), klr, rtol=2e-5, atol=1e-4)
+    assert torch.equal(zb, z.to(bt))
+    # the two dense layers on the kernel's own bf16 latent (what the split path feeds them too)
+    zq = zb.float().cpu().numpy().astype(np.float64)
+    t = no.activation(zq @ wd.astype(np.float64).T * scd + shd, 'elu')
+    tq = _bf16_round(t.astype(np.float32)).astype(np.float64)
+    ref = no.activation(tq @ w1.astype(np.float64).T * sc1 + sh1, 'elu')
+    _check(h1, ref, 'bf16', 'latent_tail')
 
 
 def test_reparam_kl(L):

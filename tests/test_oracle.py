@@ -184,3 +184,12 @@ def test_torch_cpu_f32_bracket_matches_c_oracle():
     assert np.abs(lg - r['logits']).max() < 2e-4
     np.testing.assert_allclose(bce, r['bce'], rtol=1e-4)
     np.testing.assert_array_equal([tp, fp, fn], [r['tp'], r['fp'], r['fn']])
+
+
+def test_c_oracle_under_asan():
+    """The C restatement under AddressSanitizer + UBSan (oracle/Makefile `asan`: every exported routine on small odd shapes
+    with exactly-sized heap buffers).  GPU ASan does not exist on this pool; the sanitizers run on the CPU build."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+    p = subprocess.run(['make', '-C', here, '-B', 'asan'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and 'asan driver: ok' in p.stdout, p.stdout[-3000:]
