@@ -15,6 +15,8 @@
 //                  tiles (v_mfma_f32_16x16x32_bf16, weights straight from global memory: they are read once per workgroup),
 //                  folded BN + activation in the epilogues.  The first three steps are recomputed by every slice's workgroup
 //                  (a few thousand FLOPs) instead of being exchanged.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -130,6 +132,21 @@ __device__ __forceinline__ float lt_act(float t) {
     return t;
 }
 
+// Up to 8 output tiles x 2 k-steps of weight fragments of one wave, loaded as ONE burst (16 independent 16-byte loads per lane):
+// the dense layers here are a few MFMAs behind a memory round trip, so every load that can be in flight at once must be.
+// Tile i of the wave is tile index t0 + 4 i (< ntiles); fragment = W[(tile*16 + lane & 15)][ks*32 + (lane >> 4)*8 ..].
+__device__ __forceinline__ void lt_load_w(uint4 (&wf)[8][2], const __bf16 *w, int ld, int row0, int t0, int ntiles, int ks0, int nk, int r16,
+                                          int kq) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = t0 + 4 * i, ks = ks0 + k;
+            wf[i][k] = (t < ntiles && ks < nk) ? *reinterpret_cast<const uint4 *>(w + (size_t)(row0 + t * 16 + r16) * ld + ks * 32 + kq * 8)
+                                               : make_uint4(0, 0, 0, 0);
+        }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,19 +157,59 @@ __global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
     float *encs = reinterpret_cast<float *>(smem);                    // [16][E] float32
     __bf16 *zs = reinterpret_cast<__bf16 *>(smem + 16 * a.E * 4);     // [16][L] bf16  (MFMA operand)
     __bf16 *ts = zs + 16 * a.L;                                       // [16][lin] bf16
+    const int r16 = lane & 15, kq = lane >> 4;
+    const __bf16 *wd = reinterpret_cast<const __bf16 *>(a.wd), *w1 = reinterpret_cast<const __bf16 *>(a.w1);
+    const int slice = a.n1 / a.nq, nk0 = a.L / 32, nk1 = a.lin / 32, nt0 = a.lin / 16, nt1 = slice / 16;
 
-    // ---- A: encoder output = slabs summed in slice order
+    // the weights (and the sampling noise) do not depend on the data: the first burst of both dense layers is in flight while the
+    // slabs are summed
+    float epsv[4] = {0.f, 0.f, 0.f, 0.f};          // this thread's noise values: row tid >> 4, columns (tid & 15) + 16 k  (L <= 64; else re-read)
+    if (a.variational && b0 + (tid >> 4) < a.batch) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((tid & 15) + 16 * k < a.L) epsv[k] = a.eps[(size_t)(b0 + (tid >> 4)) * a.L + (tid & 15) + 16 * k];
+    }
+    uint4 wA[8][2], wB[8][2];
+    lt_load_w(wA, wd, a.L, 0, wave, nt0, 0, nk0, r16, kq);
+    lt_load_w(wB, w1, a.lin, q * slice, wave, nt1, 0, nk1, r16, kq);
+
+    // ---- A: encoder output = slabs summed in slice order.  A thread owns up to two (row, channel quad) items and keeps the
+    // loads of BOTH in flight (8 slices each per round): the sum is a chain of memory round trips and nothing else.
     const int e4 = a.E >> 2;
-    for (int i = tid; i < 16 * e4; i += 256) {
-        const int r = i / e4, c4 = i - r * e4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        if (b0 + r < a.batch) {
-            for (int sl = 0; sl < a.nslice; ++sl)
-                s += *reinterpret_cast<const f32x4 *>(a.slabs + ((size_t)sl * a.batch + b0 + r) * a.E + c4 * 4);
-            if (a.e5_scale) s *= *reinterpret_cast<const f32x4 *>(a.e5_scale + c4 * 4);
-            if (a.enc_out && q == 0) *reinterpret_cast<f32x4 *>(a.enc_out + (size_t)(b0 + r) * a.E + c4 * 4) = s;
+    for (int i0 = tid; i0 < 16 * e4; i0 += 512) {
+        f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const float *src[2];
+        bool on[2];
+        int rr[2], cc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + 256 * u;
+            rr[u] = i / e4; cc[u] = i - rr[u] * e4;
+            on[u] = i < 16 * e4 && b0 + rr[u] < a.batch;
+            src[u] = a.slabs + (size_t)(b0 + (on[u] ? rr[u] : 0)) * a.E + (on[u] ? cc[u] : 0) * 4;
         }
-        *reinterpret_cast<f32x4 *>(encs + r * a.E + c4 * 4) = s;
+        const size_t sstride = (size_t)a.batch * a.E;
+        for (int sl0 = 0; sl0 < a.nslice; sl0 += 8) {
+            f32x4 v[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    v[u][k] = (on[u] && sl0 + k < a.nslice) ? *reinterpret_cast<const f32x4 *>(src[u] + (size_t)(sl0 + k) * sstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s[u] += v[u][k];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (i0 + 256 * u >= 16 * e4) continue;
+            if (on[u]) {
+                if (a.e5_scale) s[u] *= *reinterpret_cast<const f32x4 *>(a.e5_scale + cc[u] * 4);
+                if (a.enc_out && q == 0) *reinterpret_cast<f32x4 *>(a.enc_out + (size_t)(b0 + rr[u]) * a.E + cc[u] * 4) = s[u];
+            }
+            *reinterpret_cast<f32x4 *>(encs + rr[u] * a.E + cc[u] * 4) = s[u];
+        }
     }
     __syncthreads();
     // ---- B: slice | clip | sampling | KL: 16 lanes per sample row
@@ -167,7 +224,10 @@ __global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
                 float lv = encs[r * a.E + a.L + j];
                 lv = fminf(fmaxf(lv, -10.f), 10.f);                                   // nolbo.py:1420
                 const float e = expf(lv);
-                zz = mu + sqrtf(e) * (live ? a.eps[(size_t)(b0 + r) * a.L + j] : 0.f);   // function.py:37
+                const int kk = j >> 4;
+                const float ev = kk < 4 ? (kk == 0 ? epsv[0] : kk == 1 ? epsv[1] : kk == 2 ? epsv[2] : epsv[3])
+                                        : (live ? a.eps[(size_t)(b0 + r) * a.L + j] : 0.f);
+                zz = mu + sqrtf(e) * ev;                                              // function.py:37
                 s += 0.5f * (0.f - lv) + (e + mu * mu) / 2.0f - 0.5f;                 // function.py:96, target N(0, I)
             } else {
                 zz = encs[r * a.E + j];
@@ -183,49 +243,59 @@ __global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
         if (a.kl && a.variational && live && q == 0 && l16 == 0) a.kl[b0 + r] = s;
     }
     __syncthreads();
-    // ---- C: t = act(BN(z Wd^T + b)): weights first, D[n][row]; lane = row (lane & 15), registers = 4 consecutive outputs
-    const int r16 = lane & 15, kq = lane >> 4;
-    for (int nt = wave; nt < a.lin / 16; nt += 4) {
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < a.L / 32; ++ks) {
-            const uint4 wf = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.wd) + (size_t)(nt * 16 + r16) * a.L + ks * 32 + kq * 8);
-            const uint4 xf = *reinterpret_cast<const uint4 *>(zs + r16 * a.L + ks * 32 + kq * 8);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf), *reinterpret_cast<const bf16x8 *>(&xf), c, 0, 0, 0);
-        }
-        const int n = nt * 16 + kq * 4;
-        const f32x4 sc = a.scale_d ? *reinterpret_cast<const f32x4 *>(a.scale_d + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 sh = a.shift_d ? *reinterpret_cast<const f32x4 *>(a.shift_d + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x4 o;
+
+    // One dense layer on 16 rows: out[row][n] = act((x[row][:] . W[n][:]) * scale[n] + shift[n]) for the wave's tiles t0 + 4 i.
+    // Weights first (D[n][row]): lane = row (lane & 15), registers = 4 consecutive outputs.  `pre` holds the burst for tiles
+    // t0 .. t0 + 28 and k-steps 0, 1; anything beyond (wider layers) is fetched in further bursts.
+    auto dense16 = [&](const __bf16 *x, int K, int nk, const __bf16 *w, int row0, int ntiles, uint4 (&pre)[8][2], const float *scale,
+                       const float *shift, int nbase, auto &&store) {
+        for (int tb = wave; tb < ntiles; tb += 32) {
+            f32x4 c[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(lt_act<ACT>(c[e] * sc[e] + sh[e]));
-        *reinterpret_cast<bf16x4 *>(ts + r16 * a.lin + n) = o;
-    }
+            for (int i = 0; i < 8; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks0 = 0; ks0 < nk; ks0 += 2) {
+                if (tb != wave || ks0 != 0) lt_load_w(pre, w, K, row0, tb, ntiles, ks0, nk, r16, kq);
+                uint4 xf[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    xf[k] = ks0 + k < nk ? *reinterpret_cast<const uint4 *>(x + r16 * K + (ks0 + k) * 32 + kq * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&pre[i][k]),
+                                                                       *reinterpret_cast<const bf16x8 *>(&xf[k]), c[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = tb + 4 * i;
+                if (t >= ntiles) continue;
+                const int n = t * 16 + kq * 4;            // local output index
+                const f32x4 sc = scale ? *reinterpret_cast<const f32x4 *>(scale + nbase + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 sh = shift ? *reinterpret_cast<const f32x4 *>(shift + nbase + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(lt_act<ACT>(c[i][e] * sc[e] + sh[e]));
+                store(n, o);
+            }
+        }
+    };
+    // ---- C: t = act(BN(z Wd^T + b))
+    dense16(zs, a.L, nk0, wd, 0, nt0, wA, a.scale_d, a.shift_d, 0, [&](int n, bf16x4 o) { *reinterpret_cast<bf16x4 *>(ts + r16 * a.lin + n) = o; });
     __syncthreads();
     // ---- D: this workgroup's slice of the seed: h1[:, q*slice .. ) = act(BN(t W1^T))
-    const int slice = a.n1 / a.nq, nk = a.lin / 32;
-    for (int nt = wave; nt < slice / 16; nt += 4) {
-        const int nbase = q * slice + nt * 16;
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nk; ++ks) {
-            const uint4 wf = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.w1) + (size_t)(nbase + r16) * a.lin + ks * 32 + kq * 8);
-            const uint4 xf = *reinterpret_cast<const uint4 *>(ts + r16 * a.lin + ks * 32 + kq * 8);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf), *reinterpret_cast<const bf16x8 *>(&xf), c, 0, 0, 0);
-        }
-        const int n = nbase + kq * 4;
-        const f32x4 sc = a.scale_1 ? *reinterpret_cast<const f32x4 *>(a.scale_1 + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 sh = a.shift_1 ? *reinterpret_cast<const f32x4 *>(a.shift_1 + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(lt_act<ACT>(c[e] * sc[e] + sh[e]));
-        if (b0 + r16 < a.batch) *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(a.h1) + (size_t)(b0 + r16) * a.n1 + n) = o;
-    }
+    dense16(ts, a.lin, nk1, w1, q * slice, nt1, wB, a.scale_1, a.shift_1, q * slice, [&](int n, bf16x4 o) {
+        if (b0 + r16 < a.batch) *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(a.h1) + (size_t)(b0 + r16) * a.n1 + q * slice + n) = o;
+    });
 }
 
 struct LtPlan { int kslice, nslice, nq; size_t ws; };
 
 LtPlan lt_plan(int batch, int K5, int E, int n1) {
     LtPlan p;
+    static const int ks_env = getenv("VV_LT_KSLICE") ? atoi(getenv("VV_LT_KSLICE")) : 0;
     int ks = (K5 + 31) / 32;                               // at most 32 slices
+    if (ks_env > ks) ks = ks_env;
     ks = ((ks + LT_KS - 1) / LT_KS) * LT_KS;
     if (ks < LT_KS) ks = LT_KS;
     p.kslice = ks;

@@ -125,7 +125,7 @@ class _ModelnetBase(object):
         Legacy form still used by the reference's train scripts (train_modelnet_category_VAE.py:83-84, body kept as
         the commented block nolbo.py:1530-1555): inputs=(x, y) without category_vectors -> (pred, loss_shape, pr, rc)."""
         if training:
-            raise NotImplementedError('getEval(training=True) is not used by any reference caller')
+            return self._getEval_training_mode(inputs, category_vectors, missing_prob, _eps, _mask, _eps2)
         if len(inputs) == 2 or category_vectors is None:
             return self._getEval_legacy(inputs, missing_prob, _eps, _mask)
         input_images, output_images, category_list = inputs
@@ -163,6 +163,56 @@ class _ModelnetBase(object):
         pred_c, _, mc = self._decode_metrics(zc_act, y)                           # :1520-1527
         self._z_category_corrected = DeviceArray(zc)
         return res + (DeviceArray(pred_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
+
+    def _train_helper(self):
+        from voxvae import train as _T
+        if getattr(self, '_trainer', None) is None:
+            import torch.distributed as dist
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+            self._trainer = _T.Trainer(self._enc_eng, self._dec_eng, self._variational, self._learning_rate, world_size=world)
+        return self._trainer
+
+    def _getEval_training_mode(self, inputs, category_vectors, missing_prob, _eps, _mask, _eps2):
+        """getEval(training=True) (reference nolbo.py:1449, 1463, 1496: `self._encoder(x, training=training)`): the same
+        algebra with BatchNorm in training mode -- batch statistics, and the moving statistics move (momentum 0.99) -- and no
+        optimisation step.  Both decoder passes run in that mode, as in the reference."""
+        tr = self._train_helper()
+        if len(inputs) == 2 or category_vectors is None:
+            x, y = self._dev(inputs[0]), self._dev(inputs[1])
+            _, _, probs, _, m = tr.forward_training_mode(x, y, None if _eps is None else self._dev(_eps))
+            return DeviceArray(probs), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
+        input_images, output_images, category_list = inputs
+        x, y, onehot = self._dev(input_images), self._dev(output_images), self._dev(category_list)
+        cats = self._dev(category_vectors)
+        B, Lz, C = x.shape[0], self._latent_dim, cats.shape[0]
+        mask = None
+        if missing_prob > 0:
+            if _mask is None:
+                _mask = np.reshape(np.random.choice(2, B * Lz, p=[missing_prob, 1. - missing_prob]), [B, Lz]).astype('float32')
+            mask = self._dev(_mask)
+
+        def fill(z):
+            if mask is None:
+                return z
+            zf = torch.empty_like(z)
+            _L.call('vv_latent_mask_fill', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), C, _L.ptr(zf), None, _L.VV_F32, B, Lz, _st())
+            return zf
+
+        z, _, probs, _, m = tr.forward_training_mode(x, y, None if _eps is None else self._dev(_eps), z_fn=fill)
+        _, acc = self._category_acc(z, cats, onehot)
+        self._z_category = DeviceArray(z)
+        res = (DeviceArray(probs), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]))
+        if missing_prob == 0.0:
+            return res + (0, 0, 0, 0, 0)
+        idx, _ = self._category_acc(z, cats, None, mask)
+        eps2 = torch.randn(B, Lz, dtype=torch.float32, device=self._device) if _eps2 is None else self._dev(_eps2)
+        zc = torch.empty_like(z)
+        _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), _L.ptr(idx), _L.ptr(eps2), _L.ptr(zc), None, _L.VV_F32,
+                B, Lz, _st())
+        _, acc_c = self._category_acc(zc, cats, onehot)
+        probs_c, _, mc = tr.decoder_training_mode(zc, y)
+        self._z_category_corrected = DeviceArray(zc)
+        return res + (DeviceArray(probs_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
 
     def _getEval_legacy(self, inputs, missing_prob, _eps, _mask):
         input_images, output_images = inputs[0], inputs[1]

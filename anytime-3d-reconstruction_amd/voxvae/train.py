@@ -322,21 +322,60 @@ class Trainer:
         enc_out = self._dense(eh[-1], enc.packed['w%d' % ne], B, fe[ne], K5, f32_out=True)
         return enc_out, (ec, eh, ebn, side, K5)
 
-    def _latent_decoder(self, enc_out, y, eps, drop_mask, drop_scale, B, inv_gb):
-        dec, dev, st, dt = self.dec, self.dev, _st(), self.dt
-        D, fd, act = dec.D, dec.filters, dec.act
-        # ---------------- latent (float32 in both modes; z_act is the decoder's operand)
-        Lz = dec.L
+    def _latent(self, enc_out, eps, drop_mask, drop_scale, B):
+        """slice | clip | sampling | dropout | KL (float32 in both modes; z_act is the decoder's operand)."""
+        Lz = self.dec.L
         if self.var:
             if eps is None:
-                eps = torch.randn(B, Lz, dtype=torch.float32, device=dev)
-            z, z_act, kl, _, _ = E.reparam_kl(enc_out, eps, Lz, dt, drop_mask, drop_scale)
+                eps = torch.randn(B, Lz, dtype=torch.float32, device=self.dev)
+            z, z_act, kl, _, _ = E.reparam_kl(enc_out, eps, Lz, self.dt, drop_mask, drop_scale)
         else:
             z, kl = enc_out, None
             z_act = self._cast(z)
             if drop_mask is not None:
                 raise NotImplementedError('latent dropout for the AE class')
+        return z, z_act, kl, eps
 
+    def forward_training_mode(self, x, y, eps=None, z_fn=None):
+        """The model called with training=True and NO optimisation step (getEval(training=True), reference nolbo.py:1449,
+        1463, 1496): BatchNorm normalises with the batch statistics and updates its moving statistics, nothing else changes.
+        z_fn(z float32 [B,L]) -> z may edit the latent before the decoder (missing-latent masking).
+        Returns (z, kl or None, probs, stats [B,4], metrics [4])."""
+        self.enc.ensure_packed(fold=False)
+        self.dec.ensure_packed(fold=False)
+        B = x.shape[0]
+        enc_out, _ = self._encoder_forward(x, B)
+        z, z_act, kl, _ = self._latent(enc_out, eps, None, 1.0, B)
+        if z_fn is not None:
+            z = z_fn(z)
+            z_act = self._cast(z)
+        fw = self._decoder_forward(z_act, y, B)
+        return z, kl, fw['probs'], fw['stats'], fw['metrics']
+
+    def decoder_training_mode(self, z, y):
+        """Decoder half of forward_training_mode for an edited latent (the corrected pass of getEval)."""
+        self.dec.ensure_packed(fold=False)
+        fw = self._decoder_forward(self._cast(z), y, z.shape[0])
+        return fw['probs'], fw['stats'], fw['metrics']
+
+    def _latent_decoder(self, enc_out, y, eps, drop_mask, drop_scale, B, inv_gb):
+        dec, dev, st, dt = self.dec, self.dev, _st(), self.dt
+        D, fd, act = dec.D, dec.filters, dec.act
+        Lz = dec.L
+        z, z_act, kl, eps = self._latent(enc_out, eps, drop_mask, drop_scale, B)
+        fw = self._decoder_forward(z_act, y, B)
+        S, ch = dec.S, dec.ch
+        lin, n1 = S ** 3 * ch, S ** 3 * fd[0]
+        c_d0, t0, bn_d0, c_d1, bn_d1 = fw['c_d0'], fw['t0'], fw['bn_d0'], fw['c_d1'], fw['bn_d1']
+        dc_, dh_, dbn, probs, stats, metrics, side = fw['dc_'], fw['dh_'], fw['dbn'], fw['probs'], fw['stats'], fw['metrics'], fw['side']
+        nd = len(fd) - 1
+        w5 = dec.params['convT%d/kernel' % nd]
+        return self._decoder_backward_rest(locals())
+
+    def _decoder_forward(self, z_act, y, B):
+        dec, dev, st, dt = self.dec, self.dev, _st(), self.dt
+        D, fd, act = dec.D, dec.filters, dec.act
+        Lz = dec.L
         # ---------------- decoder forward
         S, ch = dec.S, dec.ch
         lin = S ** 3 * ch
@@ -361,7 +400,17 @@ class Trainer:
         L.call('vv_convT3d_final_bce_fwd', L.ptr(dh_[-1]), L.ptr(w5), L.ptr(y), L.ptr(probs), None, L.ptr(stats), B, side, fd[nd - 1],
                0.6, 1e-7, dt, L.ptr(ws), ws.numel(), st)
         metrics = E.shape_metrics(stats)
+        return {'c_d0': c_d0, 't0': t0, 'bn_d0': bn_d0, 'c_d1': c_d1, 'bn_d1': bn_d1, 'dc_': dc_, 'dh_': dh_, 'dbn': dbn, 'probs': probs,
+                'stats': stats, 'metrics': metrics, 'side': side}
 
+    def _decoder_backward_rest(self, fwd):
+        """Backward half of _latent_decoder; `fwd` = its locals (forward intermediates)."""
+        dec, dev, st, dt = self.dec, self.dev, _st(), self.dt
+        D, fd, act = dec.D, dec.filters, dec.act
+        B, y, inv_gb, enc_out, eps, z, z_act, kl = (fwd[k] for k in ('B', 'y', 'inv_gb', 'enc_out', 'eps', 'z', 'z_act', 'kl'))
+        drop_mask, drop_scale, Lz, S, ch, lin, n1, nd, w5 = (fwd[k] for k in ('drop_mask', 'drop_scale', 'Lz', 'S', 'ch', 'lin', 'n1', 'nd', 'w5'))
+        c_d0, t0, bn_d0, c_d1, bn_d1 = (fwd[k] for k in ('c_d0', 't0', 'bn_d0', 'c_d1', 'bn_d1'))
+        dc_, dh_, dbn, probs, stats, metrics, side = (fwd[k] for k in ('dc_', 'dh_', 'dbn', 'probs', 'stats', 'metrics', 'side'))
         # ---------------- backward: decoder tail
         dlogit = self._empty(B, D, D, D, 1)
         L.call('vv_bce_bwd', L.ptr(probs), L.ptr(y), L.ptr(dlogit), B, D ** 3, 0.6, 1e-7, inv_gb, st)
@@ -404,7 +453,7 @@ class Trainer:
         else:
             de = dz
         if self.debug is not None:
-            self.debug.update({'dlogit': dlogit, 'probs': probs, 'enc_out': enc_out, 'z': z, 'dz': dz, 'de': de, 'c_d0': c_d0,
+            self.debug.update({'dlogit': dlogit, 'probs': probs, 'enc_out': enc_out, 'z': z, 'dz': dz, 'de': de, 'c_d0': c_d0, 'dcv0': dcv0,
                                't0': t0, 'dt0': dt0, 'h_dec': dh_, 'c_dec': dc_})
         return kl, stats, metrics, de
 

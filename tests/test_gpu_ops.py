@@ -285,7 +285,10 @@ def test_convT3d_final_bce(L, dtname, B, side, form, monkeypatch):
     L.call('vv_convT3d_final_bce_metrics_fwd', L.ptr(xd), L.ptr(wd), L.ptr(yd), L.ptr(probs), L.ptr(logits), L.ptr(stats2), L.ptr(out2),
            B, side, 64, 0.6, 1e-7, dt, L.ptr(ws), ws.numel(), _st())
     torch.cuda.synchronize()
-    assert torch.equal(stats2, stats)
+    # (the fused launch adds a sample's partial blocks in block order, the two-launch form lane-strided + a wave tree: the counts
+    # are exact either way, the loss may differ in its last bits)
+    assert torch.equal(stats2[:, 1:], stats[:, 1:])
+    np.testing.assert_allclose(stats2[:, 0].cpu().numpy(), stats[:, 0].cpu().numpy(), rtol=2e-6)
     np.testing.assert_allclose(out2.cpu().numpy(), o, rtol=2e-6)
 
 

@@ -37,6 +37,7 @@ def test_fit_step_matches_autograd_oracle(D, Lz, var, B):
     from oracle import torch_oracle as to
     cfg, ep, dp, model, x, eps = _setup(D, Lz, var, B)
     ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=var)
+    model._train_helper().debug = {}                     # keep the step's intermediates (d loss / d pre-BN dense output below)
     out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
     torch.cuda.synchronize()
     vals = [float(v) for v in out]
@@ -49,8 +50,13 @@ def test_fit_step_matches_autograd_oracle(D, Lz, var, B):
     worst = {}
     for name in ref['grads']:
         g = tr.grads.views[name].cpu().numpy()
-        if name == 'dec/dense/bias':        # a bias in front of BatchNorm has zero gradient (what is left is float32 cancellation noise): compare absolutely
-            assert np.abs(g).max() < 1e-4 and np.abs(ref['grads'][name]).max() < 1e-9
+        if name == 'dec/dense/bias':
+            # a bias in front of BatchNorm has zero true gradient; what the kernel leaves is the float32 cancellation residue of
+            # a column sum of B terms of magnitude |d pre-BN|: bound it by that magnitude (a few ulps of the summands), not
+            # by a bare constant
+            assert np.abs(ref['grads'][name]).max() < 1e-9
+            scale = float(tr.debug['dcv0'].float().abs().max())
+            assert np.abs(g).max() <= 64 * np.finfo(np.float32).eps * B * scale, (np.abs(g).max(), scale)
             continue
         worst[name] = _rel(g, ref['grads'][name])
     bad = {k: v for k, v in worst.items() if v > 2e-3}
@@ -142,6 +148,7 @@ def test_bf16_mixed_precision_fit_tracks_the_oracle(D, Lz, var, B):
     from oracle import torch_oracle as to
     cfg, ep, dp, model, x, eps = _setup(D, Lz, var, B, dtype='bf16')
     ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=var)
+    model._train_helper().debug = {}                     # keep the step's intermediates (d loss / d pre-BN dense output below)
     out = model.fit((x, x), _eps=eps) if var else model.fit((x, x))
     torch.cuda.synchronize()
     vals = [float(v) for v in out]
@@ -215,3 +222,62 @@ def test_data_parallel_step_two_ranks():
         np.testing.assert_array_equal(out[0][n], out[1][n])
     np.testing.assert_array_equal(out['w0'], out['w1'])
     assert out['launch0'] == sorted(out['launch0']) and len(out['launch0']) >= 1
+
+
+def test_fit_step_with_latent_dropout_matches_autograd_oracle():
+    """The `_dr` training path (reference nolbo.py:1423-1425: rate ~ U[0,1), inverted dropout on z): mask and rate injected,
+    every gradient through the masked sampling step against the float64 autograd oracle."""
+    from oracle import torch_oracle as to
+    import src.module.nolbo as nolbo
+    cfg, ep, dp, _, x, eps = _setup(16, 64, True, 5, seed=4)
+    model = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg, dropout=True, learning_rate=1e-3)
+    model._encoder.set_weights_dict(ep)
+    model._decoder.set_weights_dict(dp)
+    rate = 0.35
+    mask = (np.random.default_rng(9).random((5, 64)) >= rate).astype(np.float32)
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=True, drop_mask=mask, drop_scale=1.0 / (1.0 - rate))
+    out = [float(v) for v in model.fit((x, x), _eps=eps, _mask=mask, _rate=rate)]
+    torch.cuda.synchronize()
+    assert abs(out[0] - ref['loss_kl']) <= 1e-4 * max(1.0, abs(ref['loss_kl']))
+    assert abs(out[1] - ref['loss_shape']) <= 2e-4 * abs(ref['loss_shape'])
+    tr = model._trainer
+    worst = {}
+    for name in ref['grads']:
+        if name == 'dec/dense/bias':
+            continue
+        worst[name] = _rel(tr.grads.views[name].cpu().numpy(), ref['grads'][name])
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, 'gradient mismatch with latent dropout (max rel err): %s' % bad
+    # the encoder's gradients flow only through the kept latent entries: a wrong mask in the backward would show here first
+    assert worst['enc/conv4/kernel'] < 2e-3
+
+
+def test_getEval_training_true_uses_batch_statistics_and_moves_the_moving_ones():
+    """getEval(training=True) (reference nolbo.py:1449, 1463, 1496): BatchNorm in training mode, no optimisation step.
+    Predictions / loss / precision / recall against the training oracle's forward, the moving statistics against its
+    momentum-0.99 update, every trainable weight untouched."""
+    from oracle import torch_oracle as to
+    from voxvae import synthetic as syn
+    cfg, ep, dp, model, x, eps = _setup(16, 64, True, 6, seed=2)
+    oh, cats = syn.make_onehot(6, 40), syn.make_category_vectors(40, 64)
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=True)
+    out = model.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.0, _eps=eps)
+    torch.cuda.synchronize()
+    assert len(out) == 10 and out[5:] == (0, 0, 0, 0, 0)
+    np.testing.assert_allclose(np.array(out[0]), ref['probs'], rtol=0, atol=2e-5)
+    assert abs(float(out[1]) - ref['loss_shape']) <= 2e-4 * abs(ref['loss_shape'])
+    assert abs(float(out[2]) - ref['pr']) < 1e-3 and abs(float(out[3]) - ref['rc']) < 1e-3
+    new_e, new_d = model._encoder.get_weights_dict(), model._decoder.get_weights_dict()
+    for pre, new, old in (('enc/', new_e, ep), ('dec/', new_d, dp)):
+        for k, v in new.items():
+            if k.endswith(('moving_mean', 'moving_variance')):
+                np.testing.assert_allclose(v, ref['params'][pre + k], rtol=1e-4, atol=1e-6, err_msg=pre + k)
+            else:
+                np.testing.assert_array_equal(v, old[k], err_msg=pre + k)
+    # the legacy 2-input form and the missing-latent form run in that mode too
+    out2 = model.getEval(inputs=(x, x), training=True, _eps=eps)
+    assert len(out2) == 4 and np.isfinite(float(out2[1]))
+    mask = (np.random.default_rng(1).random((6, 64)) >= 0.5).astype(np.float32)
+    out3 = model.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.5, _eps=eps, _mask=mask,
+                         _eps2=syn.make_eps(6, 64, seed=5))
+    assert len(out3) == 10 and all(np.isfinite(float(v)) for v in out3[1:5] + out3[6:10])
