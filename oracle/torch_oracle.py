@@ -56,8 +56,10 @@ def _bn_train(x, gamma, beta, stats, name):
     return gamma * (x - m) / torch.sqrt(v + BN_EPS) + beta
 
 
-def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_scale=1.0):
-    """P: dict name -> torch tensor ('enc/...' and 'dec/...').  Returns (loss_kl, loss_shape, probs, stats)."""
+def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_scale=1.0, latent_fn=None):
+    """P: dict name -> torch tensor ('enc/...' and 'dec/...').  Returns (loss_kl, loss_shape, probs, stats).
+    latent_fn(enc_out) -> (z_input, extra_loss): replaces the built-in latent algebra (the class-conditional prior model,
+    reference nolbo.py:1620-1676); `loss_kl` is then extra_loss."""
     enc, dec = config['encoder'], config['decoder']
     L = config['z_category_dim']
     stats = {}
@@ -68,7 +70,9 @@ def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_s
         h = _act(_bn_train(h, P['enc/bn%d/gamma' % i], P['enc/bn%d/beta' % i], stats, 'enc/bn%d' % i), enc['activation'])
     i = len(fl) - 1
     e = _conv_same(h, P['enc/conv%d/kernel' % i], st[i]).mean(dim=(1, 2, 3))
-    if variational:
+    if latent_fn is not None:
+        z, kl = latent_fn(e)
+    elif variational:
         mu, lv = e[:, :L], torch.clamp(e[:, L:2 * L], -10.0, 10.0)
         z = mu + torch.sqrt(torch.exp(lv)) * eps
         kl = (0.5 * (0.0 - lv) + (torch.exp(lv) + mu ** 2) / 2.0 - 0.5).sum(-1).mean()
@@ -143,6 +147,61 @@ def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variatio
     return {'loss_kl': float(kl.detach()), 'loss_shape': float(shape.detach()), 'pr': float(np.mean(tp / (tp + fp + 1e-10))),
             'rc': float(np.mean(tp / (tp + fn + 1e-10))), 'grads': g, 'params': new, 'bn_stats': stats,
             'adam': {'t': t, 'm': m2, 'v': v2}, 'probs': pn}
+
+
+def fit_step_category_only(config, enc_p, dec_p, mean_prior, logvar_prior, x, y, eps, eps_prior, noise=None, drop_keep=None,
+                           drop_rate=0.0):
+    """Float64 restatement of nolboSingleObject_modelnet_category_only.fit (reference nolbo.py:1620-1676) with every random
+    draw injected: eps / eps_prior = the two sampling() normals (:1637, :1639), noise [B,L] in {0,1} or None = the
+    posterior / prior mixing mask of :1642-1648 (None: the `np.random.rand() > 0.5` branch, z itself), drop_keep / drop_rate =
+    the optional Dropout on z_input (:1650-1652).  mean_prior / logvar_prior [B,L] stand for the prior network's outputs
+    (its MLP is stock autograd code on both sides): their gradients are returned next to the encoder / decoder ones.
+      loss_kl  = mean_b KL(N(mean, exp lv) || N(mean_p, exp lv_p))        function.py:84-98, nolbo.py:1655-1658
+      loss_reg = mean_b regulizer_loss(mean_p, lv_p, 2 L)                 function.py:40-71 (no class input), nolbo.py:1663-1666
+      total    = loss_kl + loss_shape + 0.01 loss_reg                     nolbo.py:1668"""
+    L = config['z_category_dim']
+    P = {}
+    for k, v in enc_p.items():
+        P['enc/' + k] = _t(v, grad=not k.endswith(('moving_mean', 'moving_variance')))
+    for k, v in dec_p.items():
+        P['dec/' + k] = _t(v, grad=not k.endswith(('moving_mean', 'moving_variance')))
+    mp, lp = _t(mean_prior, grad=True), _t(logvar_prior, grad=True)
+    e_, ep_ = _t(eps), _t(eps_prior)
+    nz = None if noise is None else _t(noise)
+    keep = None if drop_keep is None else _t(drop_keep)
+    parts = {}
+
+    def latent(e):
+        mean, lv = e[:, :L], torch.clamp(e[:, L:2 * L], -10.0, 10.0)
+        z = mean + torch.sqrt(torch.exp(lv)) * e_
+        z_prior = mp + torch.sqrt(torch.exp(lp)) * ep_
+        z_in = z if nz is None else torch.where(nz == 1.0, z, z_prior)
+        if keep is not None:
+            z_in = z_in * keep / (1.0 - drop_rate)
+        kl = (0.5 * (lp - lv) + (torch.exp(lv) + (mean - mp) ** 2) / (2.0 * torch.exp(lp)) - 0.5).sum(-1).mean()
+        B = mp.shape[0]
+        zm = mp.reshape(B, 1, L).repeat(1, B, 1)                       # [i][j] = mean_p[i]
+        zl = lp.reshape(B, 1, L).repeat(1, B, 1)                       # [i][j] = logvar_p[i]
+        diff = (torch.abs(zm - zm.transpose(0, 1)) / torch.exp(0.5 * zl)).sum(-1) - 2.0 * L
+        reg = torch.where(diff > 0, torch.zeros_like(diff), diff ** 2).sum(-1).mean()
+        parts['kl'], parts['reg'] = kl, reg
+        return z_in, kl + 0.01 * reg
+
+    extra, shape, p, stats = forward_train(config, P, _t(x), _t(y), None, latent_fn=latent)
+    total = extra + shape
+    names = trainable_names(P)
+    grads = torch.autograd.grad(total, [P[n] for n in names] + [mp, lp], allow_unused=True)
+    g = {n: (np.zeros(P[n].shape) if gr is None else gr.numpy()) for n, gr in zip(names, grads[:-2])}
+    pn = p.detach().numpy()
+    yn = np.asarray(y, np.float64)
+    B = pn.shape[0]
+    yh = (pn >= 0.5).astype(np.float64)
+    tp = (yn * yh).reshape(B, -1).sum(-1)
+    fp = ((1 - yn) * yh).reshape(B, -1).sum(-1)
+    fn = (yn * (1 - yh)).reshape(B, -1).sum(-1)
+    return {'loss_kl': float(parts['kl'].detach()), 'loss_reg': float(parts['reg'].detach()), 'loss_shape': float(shape.detach()),
+            'pr': float(np.mean(tp / (tp + fp + 1e-10))), 'rc': float(np.mean(tp / (tp + fn + 1e-10))), 'grads': g,
+            'grad_mean_prior': grads[-2].numpy(), 'grad_logvar_prior': grads[-1].numpy(), 'bn_stats': stats}
 
 
 def eval_forward_f32(config, enc_p, dec_p, x, eps):

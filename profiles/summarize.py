@@ -57,6 +57,7 @@ def traffic(fetch_csv, write_csv, specs):
     fe, wr = _counter(fetch_csv, 'FETCH_SIZE'), _counter(write_csv, 'WRITE_SIZE')
     out = {'config': 'bench.py bf16 B=256 D=32; rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes',
            'note': 'hbm_bytes_per_launch = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 FETCH_SIZE correction, see summarize.py)',
+           'stamp': stamp(),      # bench.py quotes these numbers only while the kernel sources still hash to this
            'layers': {}}
     for spec in specs:
         layer, rest = spec.split('=')

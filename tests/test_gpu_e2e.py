@@ -158,6 +158,85 @@ def test_full_batch_256_properties(dtname):
     assert abs(iou_g - iou_c) <= 1e-3
 
 
+def test_config5_shard_full_size_fp8_properties():
+    """BASELINE.json configs[4] at its per-GPU size (64^3 VAE, fp8 MFMA path, 512 / 8 = 64 samples per rank): a sample computed
+    inside the 64-batch equals the same sample in a batch of 3, permuting the batch permutes the per-sample sums exactly, and
+    the IoU of a 4-sample subset is within 1e-3 of the C oracle's."""
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    cfg = syn.make_config(64, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x = syn.make_voxels(64, 64, seed=640)
+    eps = syn.make_eps(64, 64, seed=641)
+    big = _run(cfg, ep, dp, x, x, eps, 'fp8')
+    pick = [0, 21, 63]
+    small = _run(cfg, ep, dp, x[pick], x[pick], eps[pick], 'fp8')
+    assert np.abs(big['logits'][pick] - small['logits']).max() < 0.08 * np.abs(big['logits']).max()
+    assert np.abs(big['stats'][pick, 1:] - small['stats'][:, 1:]).max() <= 0.01 * 64 ** 3
+    perm = np.random.default_rng(5).permutation(64)
+    pb = _run(cfg, ep, dp, x[perm], x[perm], eps[perm], 'fp8')
+    np.testing.assert_array_equal(pb['stats'], big['stats'][perm])
+    sub = [0, 16, 32, 48]
+    c = co.vae_eval_forward(cfg, ep, dp, x[sub], x[sub], eps[sub])
+    s = big['stats'][sub].astype(np.float64)
+    iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3]).mean()
+    iou_c = no.iou(c['tp'].astype(np.float64), c['fp'].astype(np.float64), c['fn'].astype(np.float64)).mean()
+    print('\n[config 5 shard, B=64 64^3 fp8] IoU gpu %.6f cpu %.6f' % (iou_g, iou_c))
+    assert abs(iou_g - iou_c) <= 1e-3
+
+
+def test_config3_full_size_two_decoder_passes_properties():
+    """BASELINE.json configs[2] at its full size (batch 256, latent 16, 64^3 decoder, missing_prob 0.9 -> two decoder passes,
+    the image encoder replaced by supplied head outputs): both passes of a sample inside the 256-batch equal the same sample
+    in a batch of 4, and both passes of a 4-sample subset agree with the C oracle's decoder + losses (per-sample IoU <= 5e-3,
+    mean <= 1e-3)."""
+    import voxvae
+    from oracle import c_oracle as co
+    from voxvae import engine as E
+    from voxvae import synthetic as syn
+    B, Lz, C, D = 256, 16, 12, 64
+    dec_cfg = syn.make_config(D, Lz, True)['decoder']
+    dp = syn.make_decoder_params(dec_cfg)
+    dec = E.DecoderEngine(dec_cfg, 'bf16', DEV)
+    dec.set_params(dp)
+    rng = np.random.default_rng(31)
+    head = rng.standard_normal((B, 2 * Lz)).astype(np.float32)
+    y = syn.make_voxels(B, D, seed=19)
+    oh, cats = syn.make_onehot(B, C), syn.make_category_vectors(C, Lz)
+    eps, eps2, mask = syn.make_eps(B, Lz), syn.make_eps(B, Lz, seed=8), syn.make_mask(B, Lz, 0.9)
+    mu, lv = no.split_mean_logvar(head.astype(np.float64), Lz)
+    z = no.sampling(mu, lv, eps) * mask
+    z = np.where(z == 0, cats.astype(np.float64).mean(0)[None, :] * np.ones_like(z), z)
+    idx, _ = no._nearest_category_acc(z, cats.astype(np.float64), oh, mask=mask.astype(np.float64))
+    zc = np.where(mask == 0, cats[idx].astype(np.float64) + eps2, z)
+
+    def passes(rows):
+        yd = torch.from_numpy(y[rows]).to(DEV)
+        out = []
+        for zz in (z, zc):
+            za = torch.from_numpy(zz[rows].astype(np.float32)).to(DEV).to(torch.bfloat16)
+            _, lg, st_ = dec.forward(za, yd, want_logits=True)
+            out.append((lg[:4].cpu().numpy() if len(rows) > 4 else lg.cpu().numpy(), st_.cpu().numpy()))
+        torch.cuda.synchronize()
+        return out
+
+    allrows = list(range(B))
+    big = passes(allrows)
+    pick = [0, 1, 2, 3]
+    small = passes(pick)
+    for (lb, sb), (ls, ss) in zip(big, small):
+        assert np.abs(lb - ls).max() < 0.02 * max(1.0, np.abs(ls).max())
+        assert np.abs(sb[pick, 1:] - ss[:, 1:]).max() <= 0.002 * D ** 3
+    for k, zz in enumerate((z, zc)):
+        lg = co.decoder3D_logits(dec_cfg, dp, zz[pick].astype(np.float32))
+        _, bce, tp, fp, fn = co.sigmoid_bce_counts(lg, y[pick])
+        s = big[k][1][pick].astype(np.float64)
+        iou_g = no.iou(s[:, 1], s[:, 2], s[:, 3])
+        iou_c = no.iou(tp.astype(np.float64), fp.astype(np.float64), fn.astype(np.float64))
+        assert np.abs(iou_g - iou_c).max() <= 5e-3 and abs(iou_g.mean() - iou_c.mean()) <= 1e-3
+        np.testing.assert_allclose(s[:, 0], bce, rtol=0.02)
+
+
 @pytest.mark.parametrize('D,B', [(16, 1), (16, 33), (32, 1), (32, 3), (32, 33), (32, 45), (32, 100), (64, 5)])
 def test_ragged_batches_bf16_against_c_oracle(D, B):
     """Ragged batch sizes across the kernel-selection thresholds (direct / implicit-GEMM layers, plane / gather first layer,

@@ -281,3 +281,68 @@ def test_getEval_training_true_uses_batch_statistics_and_moves_the_moving_ones()
     out3 = model.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.5, _eps=eps, _mask=mask,
                          _eps2=syn.make_eps(6, 64, seed=5))
     assert len(out3) == 10 and all(np.isfinite(float(v)) for v in out3[1:5] + out3[6:10])
+
+
+def test_class_conditional_prior_fit_matches_autograd_oracle():
+    """SURVEY §8(f) rank 2 / reference nolbo.py:1620-1676: fit() of the class-conditional prior model -- KL to the learned
+    prior, posterior / prior mixing, the pairwise regulariser at weight 0.01 -- against the float64 restatement
+    (oracle/torch_oracle.fit_step_category_only) with every draw injected.  The prior network is replaced by a stub that
+    returns two leaf tensors, so that d total / d (prior mean, prior log-variance) can be read next to the encoder / decoder
+    gradients (the MLP behind them is stock autograd code on both sides)."""
+    import voxvae
+    from oracle import torch_oracle as to
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('f32')
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    import src.net_core.priornet as priornet
+    D, Lz, B = 16, 64, 5
+    cfg = syn.make_config(D, Lz, True)
+    cfg['prior_class'] = dict(priornet.priornet_structure, unit_num_list=[64, 32, Lz])
+    ep = syn.make_encoder_params(cfg['encoder'], seed=42, nontrivial_affine=True)
+    dp = syn.make_decoder_params(cfg['decoder'], seed=43, nontrivial_affine=True, final_gain=2.0)
+    model = nolbo.nolboSingleObject_modelnet_category_only(nolbo_structure=cfg, learning_rate=1e-3)
+    model._encoder.set_weights_dict(ep)
+    model._decoder.set_weights_dict(dp)
+    rng = np.random.default_rng(21)
+    mean_p = (rng.standard_normal((B, Lz)) * 0.5).astype(np.float32)
+    lv_p = (rng.standard_normal((B, Lz)) * 0.3).astype(np.float32)
+
+    class _Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = torch.nn.Parameter(torch.from_numpy(mean_p).to(DEV))
+            self.lv = torch.nn.Parameter(torch.from_numpy(lv_p).to(DEV))
+
+        def forward(self, onehot, training=False):
+            return self.m, self.lv
+
+    stub = _Stub()
+    model._priornet_class = stub
+    x = syn.make_voxels(B, D, seed=300)
+    oh = syn.make_onehot(B, 40)
+    eps, eps_p = syn.make_eps(B, Lz, seed=301), syn.make_eps(B, Lz, seed=302)
+    noise = (rng.random((B, Lz)) >= 0.3).astype(np.float32)
+    for mix in (True, False):
+        ref = to.fit_step_category_only(cfg, ep, dp, mean_p, lv_p, x, x, eps, eps_p, noise if mix else None)
+        model._encoder.set_weights_dict(ep)              # every case starts from the same weights
+        model._decoder.set_weights_dict(dp)
+        with torch.no_grad():
+            stub.m.copy_(torch.from_numpy(mean_p)); stub.lv.copy_(torch.from_numpy(lv_p))
+        model._trainer_c = None
+        out = [float(v) for v in model.fit((x, x, oh), _rand={'eps': eps, 'eps_prior': eps_p, 'mix': mix, 'noise': noise})]
+        torch.cuda.synchronize()
+        assert abs(out[0] - ref['loss_kl']) <= 1e-4 * max(1.0, abs(ref['loss_kl'])), (mix, out[0], ref['loss_kl'])
+        assert abs(out[1] - ref['loss_shape']) <= 2e-4 * abs(ref['loss_shape'])
+        assert abs(out[2] - ref['loss_reg']) <= 1e-4 * max(1.0, abs(ref['loss_reg'])), (mix, out[2], ref['loss_reg'])
+        assert abs(out[3] - ref['pr']) < 1e-3 and abs(out[4] - ref['rc']) < 1e-3
+        tr = model._trainer_c
+        worst = {}
+        for name in ref['grads']:
+            if name == 'dec/dense/bias':
+                continue
+            worst[name] = _rel(tr.grads.views[name].cpu().numpy(), ref['grads'][name])
+        bad = {k: v for k, v in worst.items() if v > 2e-3}
+        assert not bad, 'gradient mismatch (mix=%s): %s' % (mix, bad)
+        assert _rel(stub.m.grad.cpu().numpy(), ref['grad_mean_prior']) < 1e-3
+        assert _rel(stub.lv.grad.cpu().numpy(), ref['grad_logvar_prior']) < 1e-3
