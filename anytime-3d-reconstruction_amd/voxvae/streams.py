@@ -1,0 +1,47 @@
+"""Throughput mode for evaluation: independent batches issued round-robin on several HIP streams.
+
+One evaluation step is a chain of 13 dependent launches; several of them (the 4^3 <-> 2^3 layers, the latent tail, the
+reduction passes) are latency-bound and leave most of the chip idle, and every launch has a ramp-up and a tail.  Batches are
+independent of each other (reference test loop: test_modelnet_VAE.py:114-130 calls getEval batch after batch), so the next
+batch can fill those holes if it runs on its own stream.  Each stream needs its own engine replica: the engines own split-K /
+slab workspaces that a second in-flight step would overwrite.  Weights are replicated (53 MB per replica in bf16).
+
+    ev = StreamedEvaluator(lambda: build_model(), streams=2)
+    for x, y, eps in batches:
+        outs.append(ev.submit(x, y, eps))      # returns the step's device tensors; asynchronous
+    ev.synchronize()
+
+Measured on MI355X (32^3, batch 256, bf16): 0.570 ms/step on one stream, 0.496 on two, 0.493 on three.
+"""
+import torch
+
+
+class StreamedEvaluator:
+    def __init__(self, model_factory, streams=2, device=None):
+        if streams < 1:
+            raise ValueError('streams must be >= 1')
+        self.models = [model_factory() for _ in range(streams)]
+        self.device = torch.device(device) if device is not None else self.models[0]._device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)] if streams > 1 else [None]
+        self._next = 0
+
+    def submit(self, x, y, eps=None):
+        """Enqueue model.eval_forward_device(x, y, eps) on the next stream; x, y, eps must be ready on the caller's current
+        stream (the replica's stream waits for it).  Returns (pred, stats, metrics, kl) device tensors that are valid for
+        consumers on the caller's stream after `synchronize()` (or after waiting on `last_stream`)."""
+        i = self._next
+        self._next = (i + 1) % len(self.models)
+        s = self.streams[i]
+        if s is None:
+            return self.models[i].eval_forward_device(x, y, eps)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            out = self.models[i].eval_forward_device(x, y, eps)
+        self.last_stream = s
+        return out
+
+    def synchronize(self):
+        for s in self.streams:
+            if s is not None:
+                s.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()

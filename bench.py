@@ -5,7 +5,14 @@ One "step" = one pass of the hot path over one batch: encoder -> clip|reparam|KL
 i.e. getEval(missing_prob=0) (reference nolbo.py:1463-1501), inputs resident in HBM.  Workload = BASELINE.json
 configs[1] (ModelNet40 VAE, 32^3, batch 256, bf16); synthetic voxels + random-init weights (no dataset/weights exist).
 
-    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32|fp8] [--mode eval|train]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32|fp8] [--mode eval|train] [--streams S]
+
+Scheduling: by default the K steps (independent batches, as in the reference's test loop test_modelnet_VAE.py:114-130) are
+issued round-robin on 2 HIP streams with one engine replica per stream (voxvae/streams.py): the latency-bound launches and the
+ramp / tail of every launch of one batch are filled by the other batch's kernels (+15 % on MI355X).  Every step still runs the
+whole path on its own 256-batch inside the timed region; `single_stream` in the line is the one-batch-at-a-time rate of the
+same process, and the per-kernel roofline is taken from those launches (a kernel that shares the chip with another stream's
+kernel while its events are open says nothing about the kernel; that duration is reported as `roofline.in_timed_region`).
 
 N > 1 without a launcher: bench.py starts the ranks itself (python -m torch.distributed.run --nproc-per-node N, one rank
 per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU and relays rank 0's JSON line; it refuses loudly when
@@ -55,6 +62,8 @@ def parse(argv=None):
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
                     help="'eval' = the BASELINE.json headline (default); 'train' = fit() steps (gradients all-reduced over RCCL for N>1)")
+    ap.add_argument('--streams', type=int, default=2,
+                    help='HIP streams per GPU: independent batches are issued round-robin, one engine replica per stream (1 = one batch at a time)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="process-group backend ('nccl' = RCCL; 'gloo' with --dry-run only)")
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective rehearsal without a GPU: ranks fabricate per-rank metrics and run the same reduction code')
@@ -285,13 +294,19 @@ def main():
         m._decoder.set_weights_dict(decp)
         return m
 
-    model = build_model()
+    from voxvae.streams import StreamedEvaluator
+    nstreams = max(1, a.streams) if a.mode == 'eval' else 1
+    ev = StreamedEvaluator(build_model, streams=nstreams, device=dev)
+    model = ev.models[0]
     xh = syn.make_voxels(a.batch, a.voxel, seed=1234 + rank)
     epsh = syn.make_eps(a.batch, a.latent, seed=7 + rank)
     x = torch.from_numpy(xh).to(dev)
     eps = torch.from_numpy(epsh).to(dev)
 
-    def step():
+    def step():                                  # one batch through the whole path, on the next stream of the evaluator
+        return ev.submit(x, x, eps)
+
+    def step1():                                 # the same on the caller's stream (replica 0): per-layer timing, parity legs
         return model.eval_forward_device(x, x, eps)
 
     if a.mode == 'train':
@@ -300,23 +315,37 @@ def main():
     # ---- per-layer breakdown (outside the timed region) -> dominant kernel
     lm = {n: v for n, v, _ in workload.layer_macs(cfg)}
     dominant, breakdown = 'D4', None
+    single = None
     if not a.no_breakdown:
         for _ in range(3):                      # weight packing, allocator growth and clock ramp happen here
-            step()
+            step1()
         torch.cuda.synchronize()
         t = E.LayerTimer()
         model._enc_eng.timer = model._dec_eng.timer = t
         for _ in range(10):
-            step()
+            step1()
         torch.cuda.synchronize()
+        model._enc_eng.timer = model._dec_eng.timer = None
         breakdown = {k: round(float(np.median([e0.elapsed_time(e1) for e0, e1 in v])), 4) for k, v in t.events.items()}
         dominant = max(breakdown, key=breakdown.get)
+        if nstreams > 1:
+            # one batch at a time on one stream: the rate a caller gets from a plain getEval loop, and the dominant kernel
+            # ALONE on the chip (HIP events around its launch, 100 launches) -- what a per-kernel roofline is about
+            ti = E.LayerTimer(only=dominant)
+            model._enc_eng.timer = model._dec_eng.timer = ti
+            dt1 = time_steps(step1, 100, 20)
+            model._enc_eng.timer = model._dec_eng.timer = None
+            ev_ = ti.events[dominant][-100:]
+            single = {'streams': 1, 'value': a.batch / dt1, 'ms_per_step': 1e3 * dt1, 'steps': 100,
+                      'dominant_launch_ms': float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_])), 'dominant_launches_timed': len(ev_)}
     tm = E.LayerTimer(only=dominant)
-    model._enc_eng.timer = model._dec_eng.timer = tm
+    for m_ in ev.models:                            # the dominant kernel is timed on whichever stream it is launched on
+        m_._enc_eng.timer = m_._dec_eng.timer = tm
 
     # ---- timed region
     for _ in range(a.warmup):
         step()
+    ev.synchronize()
     tm.events.clear()
     if dist is not None:
         dist.barrier()
@@ -331,8 +360,9 @@ def main():
     nl, kms = tm.summary_ms()[dominant]
 
     # ---- the 8 metric scalars of the last step, summed over the ranks by ONE all-reduce (+ MAX of the timed region)
-    model._enc_eng.timer = model._dec_eng.timer = None
-    pred, stats, metrics, kl = step()
+    for m_ in ev.models:
+        m_._enc_eng.timer = m_._dec_eng.timer = None
+    pred, stats, metrics, kl = step1()
     torch.cuda.synchronize()
     sums, el, nranks = reduce_metrics(dist, metric_vector(stats, kl), el, dev)
 
@@ -417,20 +447,35 @@ def main():
         es = 4 if a.dtype == 'f32' else 2
         nlast = len(cfg['decoder']['filter_num_list'])
         half = (a.voxel // 2) ** 3
-        if dominant == 'D%d' % nlast:        # decoder tail + losses: reads the widest activation + target, writes probabilities
-            abytes = a.batch * (half * cfg['decoder']['filter_num_list'][-2] * es + 2 * a.voxel ** 3 * 4)
-            roof = {'bound': 'hbm', 'kernel': 'final_bce kernel (%s, layer %s)' % (a.dtype, dominant), 'achieved': abytes / (kms * 1e-3) / 1e9,
-                    'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (kms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
-        elif dominant == 'E1':               # first conv: reads the f32 occupancy grid, writes the widest encoder activation
-            abytes = a.batch * (a.voxel ** 3 * 4 + half * cfg['encoder']['filter_num_list'][0] * es)
-            roof = {'bound': 'hbm', 'kernel': 'first-layer kernel (%s, layer E1)' % a.dtype, 'achieved': abytes / (kms * 1e-3) / 1e9,
-                    'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (kms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
-        else:
-            achieved = flops / (kms * 1e-3)
+
+        def roofline_of(ms):
+            if dominant == 'D%d' % nlast:        # decoder tail + losses: reads the widest activation + target, writes probabilities
+                abytes = a.batch * (half * cfg['decoder']['filter_num_list'][-2] * es + 2 * a.voxel ** 3 * 4)
+                return {'bound': 'hbm', 'kernel': 'final_bce kernel (%s, layer %s)' % (a.dtype, dominant), 'achieved': abytes / (ms * 1e-3) / 1e9,
+                        'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (ms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
+            if dominant == 'E1':                 # first conv: reads the f32 occupancy grid, writes the widest encoder activation
+                abytes = a.batch * (a.voxel ** 3 * 4 + half * cfg['encoder']['filter_num_list'][0] * es)
+                return {'bound': 'hbm', 'kernel': 'first-layer kernel (%s, layer E1)' % a.dtype, 'achieved': abytes / (ms * 1e-3) / 1e9,
+                        'peak': 8000.0, 'unit': 'GB/s', 'frac': abytes / (ms * 1e-3) / 8e12, 'algorithmic_bytes_per_launch': abytes}
+            achieved = flops / (ms * 1e-3)
             kdt = layer_dtype(dominant)           # in 'fp8' mode only the Cin % 128 == 0 layers run fp8 operands; the rest are bf16 kernels
-            roof = {'bound': 'mfma', 'kernel': 'conv kernel (%s, layer %s)' % (kdt, dominant), 'achieved': achieved / 1e12,
+            return {'bound': 'mfma', 'kernel': 'conv kernel (%s, layer %s)' % (kdt, dominant), 'achieved': achieved / 1e12,
                     'peak': PEAK[kdt] / 1e12, 'unit': 'TFLOP/s', 'frac': achieved / PEAK[kdt], 'algorithmic_flops_per_launch': flops}
-        roof.update({'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_src, 'launch_ms': kms, 'launches_timed': nl})
+
+        # A kernel's roofline is about the kernel alone on the chip.  With several streams the timed region runs it NEXT TO the
+        # other stream's kernels, so the duration between its events there includes the share of the chip it did not have: that
+        # number is reported too (`in_timed_region`), the headline fraction is taken from the one-batch-at-a-time launches of the
+        # same process (`single_stream`).  rocprofv3 summaries of both commands are under profiles/.
+        if single is not None:
+            roof = roofline_of(single['dominant_launch_ms'])
+            roof.update({'launch_ms': single['dominant_launch_ms'], 'launches_timed': single['dominant_launches_timed'],
+                         'measured': 'HIP events on the launch stream, one batch at a time (--streams 1 leg of this run)',
+                         'in_timed_region': dict(roofline_of(kms), launch_ms=kms, launches_timed=nl,
+                                                 note='%d streams: the kernel shares the chip with the other stream while its events are open' % nstreams)})
+        else:
+            roof = roofline_of(kms)
+            roof.update({'launch_ms': kms, 'launches_timed': nl, 'measured': 'HIP events on the launch stream inside the timed region'})
+        roof.update({'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_src})
         # every MFMA layer against its own algorithmic FLOPs (the table the judge recomputes from layer_ms)
         layer_frac = None
         if breakdown:
@@ -447,7 +492,10 @@ def main():
             'config': {'workload': 'ModelNet40 VAE getEval(missing_prob=0), %d^3 voxels, latent %d, batch %d per GPU, '
                                    'encoder+reparam/KL+decoder+BCE/TP/FP/FN (BASELINE.json configs[1])' % (a.voxel, a.latent, a.batch),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world,
-                       'parallelism': 'batch-sharded x%d, no data-path collective; 8 metric scalars all-reduced once' % world},
+                       'parallelism': 'batch-sharded x%d, no data-path collective; 8 metric scalars all-reduced once' % world,
+                       'streams_per_gpu': nstreams,
+                       'scheduling': ('independent 256-batches issued round-robin on %d HIP streams, one engine replica (weights + workspaces) per stream' % nstreams)
+                                     if nstreams > 1 else 'one batch at a time on one stream'},
             'rccl_world_size': nranks, 'global_metrics': global_metrics(sums),
             'iou_delta': None if parity is None else parity['iou_delta'],
             'max_logit_err_vs_cpu_oracle': None if parity is None else parity['max_logit_err'],
@@ -457,6 +505,7 @@ def main():
                            'achieved_TFLOPs_per_gpu': fl_rec * a.batch * a.steps * world / el / world / 1e12,
                            'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},
             'roofline': roof,
+            'single_stream': single,
             'layer_ms': breakdown, 'layer_frac_of_mfma_peak': layer_frac,
             'cpu_baseline': cpu, 'cpu_baseline_torch': cpu_torch,
             'h2d_inclusive': h2d, 'config1_b4': cfg1,
