@@ -35,6 +35,9 @@ class StreamedEvaluator:
         if s is None:
             return self.models[i].eval_forward_device(x, y, eps)
         s.wait_stream(torch.cuda.current_stream(self.device))
+        for t in (x, y, eps):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(s)                 # the caller may free its inputs before this stream has read them
         with torch.cuda.stream(s):
             out = self.models[i].eval_forward_device(x, y, eps)
         self.last_stream = s

@@ -527,6 +527,8 @@ def test_streamed_evaluator_matches_one_batch_at_a_time():
     from voxvae.streams import StreamedEvaluator
     voxvae.set_default_dtype('bf16')
     import src.module.nolbo as nolbo
+    DEV = 'cuda:0'
+    voxvae.set_default_device(DEV)
     cfg = syn.make_config(32, 64, True)
     ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
 
