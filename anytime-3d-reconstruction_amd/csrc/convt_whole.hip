@@ -1,0 +1,284 @@
+// Transposed convolution 8^3 x 128 -> 16^3 x 64 with one WHOLE SAMPLE resident in LDS (bf16, gfx950).
+//
+// Conv3DTranspose k4 s2 SAME (autoencoder3D.py:41-54) in output-parity form: voxel 2m + p of the output reads the input
+// cells m + p - a, a in {0,1}^3, through tap t = 1 - p + 2a (per axis).  convt_direct.hip keeps a (4+2) x (4+2) x (8+2) halo
+// tile of 128 cells in LDS and streams the parity's weights into registers, one wave per parity: every workgroup pulls the
+// whole 1 MiB weight tensor through its CU for 128 cells (1 GiB of L2 -> CU traffic per launch at batch 256, 256 B per
+// MFMA per wave), and that instruction stream, not the MFMA pipe, sets its pace.  The input of this layer is only
+// 8^3 x 256 B = 128 KiB per sample: here the workgroup IS the sample.  No halo (out-of-grid taps read a zero row), the
+// weights cross the CU once per 512 cells (4x fewer bytes), and because all eight waves now work on the same parity they
+// share each weight chunk through an LDS ring exactly as conv_direct.hip does.
+//
+//   workgroup  : 512 threads = 8 waves; wave w owns input plane d = w: 64 cells (2 row tiles of 4 h x 8 w) x 64 channels
+//                (2 channel tiles) = 4 accumulators of 32x32; parities are processed one after the other
+//   LDS        : x tile [512 voxels][256 B], slot XOR (v & 15) -- conflict-free for every tap shift and every ds_read_b128
+//                lane group (a tap shift adds a constant mod 16 to the slot key); weights [64 co][64 ci] per (parity, tap,
+//                K half) in a 3-deep ring (slot ^ (co>>1)&7), one 1 KiB LDS-DMA piece per wave per chunk, issued three
+//                chunks ahead; a 256-byte zero row that lanes of out-of-grid cells read instead (same slot -> same bank)
+//   sync       : one barrier per chunk (16 MFMAs per wave), placed before the chunk's last k-step (conv_direct.hip's scheme)
+//   skipping   : a wave whose whole plane is out of the grid for a tap (d = -1 or 8) issues no MFMAs for it
+//   epilogue   : folded BN + activation in registers, bf16 pack, v_permlane32_swap pairs -> one 16-byte store per lane and
+//                pair of channel groups (guide T21): no LDS staging, so the next parity's weight chunks keep streaming
+//   grid       : batch x ps workgroups, ps = 1, 2, 4, 8 splits of the 8 parities (ps > 1 only to fill the chip at batch < 256)
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CW_X = 512 * 256;                    // 131,072 B: the sample
+constexpr int CW_WST = 64 * 128;                   // one weight chunk: 64 co x 64 ci
+constexpr int CW_NST = 3;
+constexpr int CW_RING = CW_X;
+constexpr int CW_ZERO = CW_RING + CW_NST * CW_WST; // 155,648
+constexpr int CW_SS = CW_ZERO + 256;               // scale[64], shift[64]
+constexpr int CW_LDS = CW_SS + 512;                // 156,416 B
+
+template <int N>
+__device__ __forceinline__ void cw_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+#define CW_LD(F, X0, X1, WA)                                                                                                     \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:4096"          \
+                 : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3])                                                            \
+                 : "v"(X0), "v"(X1), "v"(WA)                                                                                     \
+                 : "memory")
+#define CW_WAIT(F, N) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) : "n"(N) : "memory")
+#define CW_MFMA4(F)                                                                                                              \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                        \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&F[2 + nt]),                 \
+                                                                  *reinterpret_cast<const bf16x8 *>(&F[mt]), acc[nt][mt], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    } while (0)
+
+// w: vv_pack_convT_k4s2_skip's image [parity][tap][K half][64 co][64 ci]
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     __bf16 *__restrict__ y, int npar, int dbg) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ps = 8 / npar;
+    const int b = (int)blockIdx.x / ps, p0 = ((int)blockIdx.x % ps) * npar;
+    const int NC = npar * 16;                      // chunks of this workgroup
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    const u32x4 rsx = vv_make_rsrc(x + (size_t)b * (512 * 128), CW_X);
+    const u32x4 rsw = vv_make_rsrc(w, 64 * 128 * 64 * 2);
+
+    // ---- prologue: the sample (16 pieces of 4 voxels per wave, plane by plane), weight chunks 0..2, zero row, folded BN
+    {
+        const int pos = lane & 15, vsub = lane >> 4;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int it = i * 8 + wave;
+            const int v = it * 4 + vsub;
+            vv_dma16(rsx, (unsigned)(v * 256 + ((pos ^ (v & 15)) << 4)), lds0 + it * 1024);
+        }
+    }
+    // weight pieces: this wave's rows 8 wave .. 8 wave + 7 of every chunk
+    const unsigned wv = (unsigned)((wave * 8 + (lane >> 3)) * 128 + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 4));
+    auto issue_w = [&](int c, int s) {               // chunk c (clamped: the tail re-fetches the last chunk into a free stage)
+        const int cc = c < NC ? c : NC - 1;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((p0 * 16 + cc) * CW_WST);
+        vv_dma16(rsw, wv, soff, lds0 + CW_RING + s * CW_WST + wave * 1024);
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+    issue_w(2, 2);
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + CW_ZERO + tid * 16) = uint4{0u, 0u, 0u, 0u};
+    if (tid >= 64 && tid < 128) {
+        const int ch = tid - 64;
+        *reinterpret_cast<float *>(smem + CW_SS + ch * 4) = scale ? scale[ch] : 1.f;
+        *reinterpret_cast<float *>(smem + CW_SS + 256 + ch * 4) = shift ? shift[ch] : 0.f;
+    }
+    cw_wait_vm<0>();
+    __syncthreads();
+
+    // ---- consumer addressing
+    const int fr = lane & 31, fh = lane >> 5;
+    const int mh = fr >> 3, mw = fr & 7;
+    const unsigned wl = lds0 + CW_RING + fr * 128 + ((fh ^ ((fr >> 1) & 7)) << 4);     // + stage * CW_WST, ^ (k-step << 5)
+    const unsigned R0 = lds0 + (unsigned)((wave * 64 + mh * 8 + mw) << 8);             // this lane's own cell, row tile 0
+    const unsigned ZR = lds0 + CW_ZERO;
+    const int cb = mh * 8 + mw;
+    // x row address ^ slot key of the cells this lane reads for tap A of parity (pd, ph, pw), row tiles 0 / 1.  The slot key
+    // of voxel v is v & 15 = (8 zh + zw) & 15, the same for both row tiles (they are 4 h-rows = 32 voxels apart).
+    auto tap_setup = [&](auto a_c, int pd, int ph, int pw, unsigned &t0, unsigned &t1) {
+        constexpr int A = decltype(a_c)::value;
+        const int dd = pd - ((A >> 2) & 1), dh = ph - ((A >> 1) & 1), dw = pw - (A & 1);
+        const bool okw = (unsigned)(wave + dd) < 8u && (unsigned)(mw + dw) < 8u;
+        const int sft = dd * 64 + dh * 8 + dw;
+        const unsigned key = ((unsigned)((cb + dh * 8 + dw) ^ fh) & 15u) << 4;
+        const unsigned r0 = okw && (unsigned)(mh + dh) < 8u ? R0 + (unsigned)(sft << 8) : ZR;
+        const unsigned r1 = okw && (unsigned)(mh + 4 + dh) < 8u ? R0 + (unsigned)((sft + 32) << 8) : ZR;
+        t0 = r0 ^ key;
+        t1 = r1 ^ key;
+    };
+
+    f32x16 acc[2][2];                                // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- epilogue of one parity: lane = cell, registers walk channels (weights-first MFMA)
+    auto epilogue = [&](int p) {
+        const int pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        char *yb = reinterpret_cast<char *>(y) + ((((size_t)b * 16 + 2 * wave + pd) * 16) * 16) * 128 + fh * 16;
+        const char *ss = smem + CW_SS + fh * 16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            u32x2 o[2][4];                           // [mt][g]: bf16 x 4 of channels nt*32 + 8g + 4fh ..
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + (nt * 32 + 8 * g) * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(ss + 256 + (nt * 32 + 8 * g) * 4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[nt][mt][4 * g + e] * sc[e] + sh[e];
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        q[e] = static_cast<__bf16>(t);
+                        acc[nt][mt][4 * g + e] = 0.f;
+                    }
+                    o[mt][g] = *reinterpret_cast<const u32x2 *>(&q);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                char *row = yb + (size_t)(((2 * (mt * 4 + mh) + ph) * 16 + 2 * mw + pw) * 128) + nt * 64;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x2 lo = o[mt][2 * j], hi = o[mt][2 * j + 1];
+                    // lanes 32-63 of `lo` swap with lanes 0-31 of `hi`: the lower half then holds 8 consecutive channels
+                    // [own group 2j | upper's group 2j], the upper half [lower's group 2j+1 | own group 2j+1]
+                    auto rx = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+                    auto ry = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+                    *reinterpret_cast<u32x4 *>(row + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                }
+            }
+        }
+    };
+
+    // ---- main loop.  One parity = 8 taps x 2 K halves = 16 chunks, unrolled with the tap as a compile-time constant: the
+    // scalar / address work per chunk is what a wave pays next to its 16 MFMAs (measured: a generic runtime-(parity, tap)
+    // loop spent as long on it as on the MFMAs).
+    u32x4 P[4], Q[4];
+    unsigned ua0, ua1, ub0, ub1;                     // current tap's / next tap's row keys
+    tap_setup(std::integral_constant<int, 0>{}, (p0 >> 2) & 1, (p0 >> 1) & 1, p0 & 1, ua0, ua1);
+    unsigned ws = wl;                                // weight fragment base in the current chunk's stage
+    int stg = 0;                                     // that stage
+    int cw = 3;                                      // next chunk to fetch
+    CW_LD(P, ua0, ua1, ws);                          // chunk 0, k-step 0
+#pragma unroll 1
+    for (int pi = 0; pi < npar; ++pi) {
+        const int p = p0 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        const int pn = p + 1, pnd = (pn >> 2) & 1, pnh = (pn >> 1) & 1, pnw = pn & 1;
+        auto chunk = [&](auto j_c) {
+            constexpr int J = decltype(j_c)::value, A = J >> 1, KH = J & 1;
+            const unsigned x0 = KH ? ua0 ^ 128u : ua0, x1 = KH ? ua1 ^ 128u : ua1;    // K half: k-steps 4..7 are slots 8..15
+            CW_LD(Q, x0 ^ 32u, x1 ^ 32u, ws ^ 32u);
+            CW_WAIT(P, 4);
+            CW_MFMA4(P);
+            if (KH == 0) {                           // the next tap's keys, far from the barrier
+                if (A < 7) tap_setup(std::integral_constant<int, (A + 1) & 7>{}, pd, ph, pw, ub0, ub1);
+                else tap_setup(std::integral_constant<int, 0>{}, pnd, pnh, pnw, ub0, ub1);
+            }
+            CW_LD(P, x0 ^ 64u, x1 ^ 64u, ws ^ 64u);
+            CW_WAIT(Q, 4);
+            CW_MFMA4(Q);
+            CW_LD(Q, x0 ^ 96u, x1 ^ 96u, ws ^ 96u);
+            CW_WAIT(P, 4);
+            CW_MFMA4(P);
+            CW_WAIT(Q, 0);                           // every LDS read of this chunk has returned: its stage may be refilled
+            // The next chunk's piece has landed.  Issued after it: one more piece, and, in the two chunks that follow a
+            // parity's epilogue, that epilogue's 8 stores (between the pieces in the in-order counter).
+            if (J < 2 && pi > 0) cw_wait_vm<9>();
+            else cw_wait_vm<1>();
+            __builtin_amdgcn_s_barrier();
+            issue_w(cw, stg);
+            ++cw;
+            stg = stg == CW_NST - 1 ? 0 : stg + 1;
+            ws = wl + stg * CW_WST;
+            if (KH == 0) {
+                CW_LD(P, ua0 ^ 128u, ua1 ^ 128u, ws);
+            } else {
+                ua0 = ub0;
+                ua1 = ub1;
+                CW_LD(P, ua0, ua1, ws);
+            }
+            CW_MFMA4(Q);
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        chunk(std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 5>{});
+        chunk(std::integral_constant<int, 6>{});
+        chunk(std::integral_constant<int, 7>{});
+        chunk(std::integral_constant<int, 8>{});
+        chunk(std::integral_constant<int, 9>{});
+        chunk(std::integral_constant<int, 10>{});
+        chunk(std::integral_constant<int, 11>{});
+        chunk(std::integral_constant<int, 12>{});
+        chunk(std::integral_constant<int, 13>{});
+        chunk(std::integral_constant<int, 14>{});
+        chunk(std::integral_constant<int, 15>{});
+        if (!(dbg & 16)) epilogue(p);
+    }
+    CW_WAIT(P, 0);                                   // the look-ahead reads of the chunk after the last
+    cw_wait_vm<0>();                                 // the tail's pieces still target this workgroup's LDS
+}
+
+}  // namespace
+
+VV_EXPORT int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype) {
+    return dtype == VV_BF16 && side == 8 && cin == 128 && cout == 64;
+}
+
+// w_skip: vv_pack_convT_k4s2_skip's image.  One workgroup per (sample, parity split).
+VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                                        int side, int cin, int cout, int act, int dtype, void *stream) {
+    if (!x || !w_skip || !y) return VV_ERR_NULL;
+    if (!vv_convT3d_k4s2_whole_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_skip) || !vv_aligned16(y)) return VV_ERR_ALIGN;
+    int ps = 1;
+    while (ps < 8 && (long)batch * ps < 256) ps *= 2;
+    if (const char *e = getenv("VV_CTW_PS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
+    }
+    const char *de = getenv("VV_CTW_DBG");          // timing ablations only (wrong results): 16 no epilogue
+    const int dbg = de ? atoi(de) : 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto launch = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
+            return true;
+        }();
+        (void)attr;
+        VV_LAUNCH(ctw_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
+                  reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
+    };
+    switch (act) {
+        case VV_ACT_ELU: launch(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: launch(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: launch(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: launch(std::integral_constant<int, VV_ACT_NONE>{}); break;
+    }
+    return vv_launch_status();
+}

@@ -54,6 +54,8 @@ SIGNATURES = {
     'vv_pack_convT_k4s2_skip': (_i, [_vp, _vp, _i, _i, _vp]),
     'vv_conv3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_convT3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'vv_convT3d_k4s2_whole_supported': (_i, [_i, _i, _i, _i]),
+    'vv_convT3d_k4s2_whole_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_conv3d_k4s2_pos_supported': (_i, [_i, _i, _i, _i]),
     'vv_convT3d_k4s2_pos_supported': (_i, [_i, _i, _i, _i]),
     'vv_conv3d_k4s2_pos_workspace_bytes': (_sz, [_i, _i, _i]),

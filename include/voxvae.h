@@ -154,6 +154,15 @@ int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scal
 int vv_convT3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
                              int side, int cin, int cout, int act, int dtype, void *stream);
 
+/* conv3DDec 8^3 x 128 -> 16^3 x 64 (autoencoder3D.py:41-54; the 32^3 model's widest decoder layer) with one WHOLE sample
+ * resident in LDS per workgroup (128 KiB, no halo: out-of-grid taps read a zero row), all eight waves on the same output
+ * parity sharing each weight chunk through an LDS ring (bf16 only).  w_skip = vv_pack_convT_k4s2_skip's image.  One
+ * workgroup per (sample, parity split); the 8 parities are split over 2 / 4 / 8 workgroups when the batch alone would not
+ * fill the chip (VV_CTW_PS overrides).  Replaces vv_convT3d_k4s2_direct_fwd at this shape; no workspace. */
+int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype);
+int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
+                              int side, int cin, int cout, int act, int dtype, void *stream);
+
 /* conv3DEnc / conv3DDec between the 4^3 and the 2^3 grid (the 32^3 model's 256 -> 512 and 512 -> 256 layers) as a
  * position-major split-K GEMM: rows = the batch at one output position, K = that position's valid (tap, 64-channel chunk)
  * pairs cut into equal shares over the workgroups, 256 x 128 tiles, 3-stage LDS-DMA ring (bf16 only).  Weights in the

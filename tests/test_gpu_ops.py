@@ -136,6 +136,39 @@ def test_convT3d_k4s2_skip(L, B, cin, cout, act):
     _check(y, ref, 'bf16', 'convT3d_k4s2_skip')
 
 
+# whole-sample transposed convolution 8^3 x 128 -> 16^3 x 64 (convt_whole.hip): every parity split, every activation,
+# batches that are not a multiple of anything, null scale / shift; compared against the float64 definition
+@pytest.mark.parametrize('ps', [0, 1, 2, 4, 8])
+@pytest.mark.parametrize('B,act', [(3, 1), (7, 0), (33, 2), (5, 3)])
+def test_convT3d_k4s2_whole(L, B, act, ps, monkeypatch):
+    cin, cout = 128, 64
+    rng = np.random.default_rng(B * 23 + act)
+    x = _bf16_round(rng.standard_normal((B, 8, 8, 8, cin)).astype(np.float32))
+    w = _bf16_round((rng.standard_normal((4, 4, 4, cout, cin)) / np.sqrt(8 * cin)).astype(np.float32))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.3, cout).astype(np.float32)
+    assert L.load().vv_convT3d_k4s2_whole_supported(8, cin, cout, L.VV_BF16)
+    assert not L.load().vv_convT3d_k4s2_whole_supported(16, cin, cout, L.VV_BF16)
+    ref = no.activation(no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2) * scale + shift,
+                        {0: None, 1: 'elu', 2: 'relu', 3: 'lrelu'}[act])
+    xd, wd, scd, shd = _dev(x, torch.bfloat16), _dev(w), _dev(scale), _dev(shift)
+    wp = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_skip', L.ptr(wd), L.ptr(wp), cin, cout, _st())
+    y = torch.full((B, 16, 16, 16, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    if ps:
+        monkeypatch.setenv('VV_CTW_PS', str(ps))
+    else:
+        monkeypatch.delenv('VV_CTW_PS', raising=False)
+    L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(xd), L.ptr(wp), L.ptr(scd), L.ptr(shd), L.ptr(y), B, 8, cin, cout, act, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    _check(y, ref, 'bf16', 'convT3d_k4s2_whole')
+    if ps in (0, 8):                                  # null scale / shift = identity
+        y2 = torch.full_like(y, float('nan'))
+        L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(xd), L.ptr(wp), None, None, L.ptr(y2), B, 8, cin, cout, 0, L.VV_BF16, _st())
+        torch.cuda.synchronize()
+        _check(y2, no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2), 'bf16', 'convT3d_k4s2_whole (no BN)')
+
+
 # position-major split-K GEMM of the 4^3 <-> 2^3 layers (posgemm.hip): ragged batches, channel tails, several sample tiles
 @pytest.mark.parametrize('act', [1, 0])
 @pytest.mark.parametrize('B,cin,cout', [(5, 64, 64), (37, 256, 512), (256, 128, 136), (300, 64, 128)])
