@@ -243,6 +243,202 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
     cw_wait_vm<0>();                                 // the tail's pieces still target this workgroup's LDS
 }
 
+
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16: same LDS images, same chunk / ring / barrier scheme; a wave's 64 x 64 tile
+// is 4 x 4 accumulators of 16 x 16 (16 cells = two h-rows, 16 channels), 8 fragment reads and 16 MFMAs per 32-deep k-step.
+// On random data the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
+#define CW16_LD(F, XA, WA)                                                                                                          \
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"                    \
+                 "ds_read_b128 %4, %12\n\tds_read_b128 %5, %12 offset:2048\n\tds_read_b128 %6, %12 offset:4096\n\t"                  \
+                 "ds_read_b128 %7, %12 offset:6144"                                                                                 \
+                 : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3]), "=&v"(F[4]), "=&v"(F[5]), "=&v"(F[6]), "=&v"(F[7])            \
+                 : "v"(XA[0]), "v"(XA[1]), "v"(XA[2]), "v"(XA[3]), "v"(WA)                                                           \
+                 : "memory")
+#define CW16_WAIT(F, N)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                            \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])                    \
+                 : "n"(N)                                                                                                           \
+                 : "memory")
+#define CW16_MFMA(F)                                                                                                                \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int cot = 0; cot < 4; ++cot) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                        \
+            acc[cot][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + cot]),                  \
+                                                                   *reinterpret_cast<const bf16x8 *>(&F[ct]), acc[cot][ct], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    } while (0)
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       __bf16 *__restrict__ y, int npar, int dbg) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ps = 8 / npar;
+    const int b = (int)blockIdx.x / ps, p0 = ((int)blockIdx.x % ps) * npar;
+    const int NC = npar * 16;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    const u32x4 rsx = vv_make_rsrc(x + (size_t)b * (512 * 128), CW_X);
+    const u32x4 rsw = vv_make_rsrc(w, 64 * 128 * 64 * 2);
+    {
+        const int pos = lane & 15, vsub = lane >> 4;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int it = i * 8 + wave;
+            const int v = it * 4 + vsub;
+            vv_dma16(rsx, (unsigned)(v * 256 + ((pos ^ (v & 15)) << 4)), lds0 + it * 1024);
+        }
+    }
+    const unsigned wv = (unsigned)((wave * 8 + (lane >> 3)) * 128 + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 4));
+    auto issue_w = [&](int c, int s) {
+        const int cc = c < NC ? c : NC - 1;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((p0 * 16 + cc) * CW_WST);
+        vv_dma16(rsw, wv, soff, lds0 + CW_RING + s * CW_WST + wave * 1024);
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+    issue_w(2, 2);
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + CW_ZERO + tid * 16) = uint4{0u, 0u, 0u, 0u};
+    if (tid >= 64 && tid < 128) {
+        const int ch = tid - 64;
+        *reinterpret_cast<float *>(smem + CW_SS + ch * 4) = scale ? scale[ch] : 1.f;
+        *reinterpret_cast<float *>(smem + CW_SS + 256 + ch * 4) = shift ? shift[ch] : 0.f;
+    }
+    cw_wait_vm<0>();
+    __syncthreads();
+
+    // ---- consumer addressing: lane = (r, q): row r of a 16-row fragment, k quarter q
+    const int r = lane & 15, q = lane >> 4;
+    const int rh = r >> 3, rw = r & 7;
+    const unsigned wl = lds0 + CW_RING + r * 128 + ((q ^ ((r >> 1) & 7)) << 4);        // + stage, + 2048 cot, ^ (k-step << 6)
+    const unsigned R0 = lds0 + (unsigned)((wave * 64 + r) << 8);                       // this lane's own cell, cell tile 0
+    const unsigned ZR = lds0 + CW_ZERO;
+    // x row address ^ slot key of the 4 cells (cell tiles 0..3: h-rows 2 ct, 2 ct + 1) this lane reads for tap A
+    auto tap_setup = [&](auto a_c, int pd, int ph, int pw, unsigned (&t)[4]) {
+        constexpr int A = decltype(a_c)::value;
+        const int dd = pd - ((A >> 2) & 1), dh = ph - ((A >> 1) & 1), dw = pw - (A & 1);
+        const bool okw = (unsigned)(wave + dd) < 8u && (unsigned)(rw + dw) < 8u;
+        const int sft = dd * 64 + dh * 8 + dw;
+        const unsigned key = ((unsigned)((r + dh * 8 + dw) ^ q) & 15u) << 4;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const unsigned row = okw && (unsigned)(2 * ct + rh + dh) < 8u ? R0 + (unsigned)((sft + 16 * ct) << 8) : ZR;
+            t[ct] = row ^ key;
+        }
+    };
+
+    f32x4 acc[4][4];                                 // [cot][ct]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- epilogue of one parity: lane (r, q) holds channels 16 cot + 4 q .. + 3 of cell 16 ct + r.  v_permlane16_swap of
+    // the channel tiles (2c, 2c+1) gives every lane 8 consecutive channels: q = 0: tile 2c ch 0..7, 1: tile 2c+1 ch 0..7,
+    // 2: tile 2c ch 8..15, 3: tile 2c+1 ch 8..15 -> one 16-byte store per lane and tile pair.
+    auto epilogue = [&](int p) {
+        const int pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        const int qo = (q & 1) * 32 + (q >> 1) * 16;
+        char *yb = reinterpret_cast<char *>(y) + ((((size_t)b * 16 + 2 * wave + pd) * 16 + 2 * rh + ph) * 16 + 2 * rw + pw) * 128 + qo;
+        const char *ss = smem + CW_SS + q * 16;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            u32x2 o[2][4];                           // [cot & 1][ct]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cot = 2 * c2 + h;
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + cot * 64);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(ss + 256 + cot * 64);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[cot][ct][e] * sc[e] + sh[e];
+                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                        v[e] = static_cast<__bf16>(t);
+                        acc[cot][ct][e] = 0.f;
+                    }
+                    o[h][ct] = *reinterpret_cast<const u32x2 *>(&v);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                // odd 16-lane rows of the first operand swap with the even rows of the second
+                auto rx = __builtin_amdgcn_permlane16_swap(o[0][ct][0], o[1][ct][0], false, false);
+                auto ry = __builtin_amdgcn_permlane16_swap(o[0][ct][1], o[1][ct][1], false, false);
+                *reinterpret_cast<u32x4 *>(yb + (size_t)(ct * 4 * 16 * 128) + c2 * 64) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+            }
+        }
+    };
+
+    u32x4 P[8], Q[8];
+    unsigned ua[4], ub[4];
+    tap_setup(std::integral_constant<int, 0>{}, (p0 >> 2) & 1, (p0 >> 1) & 1, p0 & 1, ua);
+    unsigned ws = wl;
+    int stg = 0, cw = 3;
+    CW16_LD(P, ua, ws);
+#pragma unroll 1
+    for (int pi = 0; pi < npar; ++pi) {
+        const int p = p0 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        const int pn = p + 1, pnd = (pn >> 2) & 1, pnh = (pn >> 1) & 1, pnw = pn & 1;
+        auto chunk = [&](auto j_c) {
+            constexpr int J = decltype(j_c)::value, A = J >> 1, KH = J & 1;
+            unsigned xq[4];                          // second 32-deep k-step of this K half: slots +4
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) xq[ct] = ua[ct] ^ (KH ? 192u : 64u);
+            CW16_LD(Q, xq, ws ^ 64u);
+            CW16_WAIT(P, 8);
+            CW16_MFMA(P);
+            if (KH == 0) {
+                if (A < 7) tap_setup(std::integral_constant<int, (A + 1) & 7>{}, pd, ph, pw, ub);
+                else tap_setup(std::integral_constant<int, 0>{}, pnd, pnh, pnw, ub);
+            }
+            CW16_WAIT(Q, 0);
+            if (J < 2 && pi > 0) cw_wait_vm<9>();
+            else cw_wait_vm<1>();
+            __builtin_amdgcn_s_barrier();
+            issue_w(cw, stg);
+            ++cw;
+            stg = stg == CW_NST - 1 ? 0 : stg + 1;
+            ws = wl + stg * CW_WST;
+            if (KH == 0) {
+                unsigned xn[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) xn[ct] = ua[ct] ^ 128u;
+                CW16_LD(P, xn, ws);
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) ua[ct] = ub[ct];
+                CW16_LD(P, ua, ws);
+            }
+            CW16_MFMA(Q);
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        chunk(std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 5>{});
+        chunk(std::integral_constant<int, 6>{});
+        chunk(std::integral_constant<int, 7>{});
+        chunk(std::integral_constant<int, 8>{});
+        chunk(std::integral_constant<int, 9>{});
+        chunk(std::integral_constant<int, 10>{});
+        chunk(std::integral_constant<int, 11>{});
+        chunk(std::integral_constant<int, 12>{});
+        chunk(std::integral_constant<int, 13>{});
+        chunk(std::integral_constant<int, 14>{});
+        chunk(std::integral_constant<int, 15>{});
+        if (!(dbg & 16)) epilogue(p);
+    }
+    CW16_WAIT(P, 0);
+    cw_wait_vm<0>();
+}
+
 }  // namespace
 
 VV_EXPORT int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype) {
@@ -263,16 +459,23 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
     }
     const char *de = getenv("VV_CTW_DBG");          // timing ablations only (wrong results): 16 no epilogue
     const int dbg = de ? atoi(de) : 0;
+    const char *se = getenv("VV_CTW_SHAPE");        // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    const bool shape16 = !se || atoi(se) != 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto launch = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;
         static const bool attr = [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw16_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
             return true;
         }();
         (void)attr;
-        VV_LAUNCH(ctw_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
-                  reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
+        if (shape16)
+            VV_LAUNCH(ctw16_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
+                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
+        else
+            VV_LAUNCH(ctw_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
+                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
     };
     switch (act) {
         case VV_ACT_ELU: launch(std::integral_constant<int, VV_ACT_ELU>{}); break;

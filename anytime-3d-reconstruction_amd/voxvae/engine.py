@@ -377,6 +377,10 @@ class DecoderEngine(_EngineBase):
             elif direct:
                 pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
                 L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
+                if not os.environ.get('VV_NO_WHOLE') and L.load().vv_convT3d_k4s2_whole_supported(side_i, f[i - 1], f[i], self.dt):
+                    # the 8^3 x 128 -> 16^3 x 64 layer of the 32^3 model: one whole sample resident in LDS per workgroup
+                    pk['ww%d' % i] = self._empty(64 * f[i - 1] * f[i])
+                    L.call('vv_pack_convT_k4s2_skip', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['ww%d' % i]), f[i - 1], f[i], st)
             elif (self._want_fold and not os.environ.get('VV_NO_SKIP')
                   and (L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)
                        or L.load().vv_convT3d_k4s2_pos_supported(side_i, f[i - 1], f[i], self.dt))):
@@ -419,6 +423,12 @@ class DecoderEngine(_EngineBase):
             name = 'D%d' % (i + 1)
             q, nq = pk.get('q%d' % i, False), pk.get('q%d' % (i + 1), False)
             odt = L.VV_FP8 if nq else self.dt
+            if ('ww%d' % i) in pk and hdt == self.dt:
+                o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
+                self._call(name, 'vv_convT3d_k4s2_whole_fwd', L.ptr(h), L.ptr(pk['ww%d' % i]), L.ptr(pk['scale%d' % i]),
+                           L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
+                h, side, hdt = o, 2 * side, self.dt
+                continue
             if ('wf%d' % i) in pk:
                 o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
                 self._call(name, 'vv_convT3d_k4s2_direct_fwd', L.ptr(h), L.ptr(pk['wf%d' % i]), L.ptr(pk['scale%d' % i]),

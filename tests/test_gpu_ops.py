@@ -138,9 +138,11 @@ def test_convT3d_k4s2_skip(L, B, cin, cout, act):
 
 # whole-sample transposed convolution 8^3 x 128 -> 16^3 x 64 (convt_whole.hip): every parity split, every activation,
 # batches that are not a multiple of anything, null scale / shift; compared against the float64 definition
+@pytest.mark.parametrize('shape', [16, 32])            # MFMA shape: 16x16x32 (default) / 32x32x16
 @pytest.mark.parametrize('ps', [0, 1, 2, 4, 8])
 @pytest.mark.parametrize('B,act', [(3, 1), (7, 0), (33, 2), (5, 3)])
-def test_convT3d_k4s2_whole(L, B, act, ps, monkeypatch):
+def test_convT3d_k4s2_whole(L, B, act, ps, shape, monkeypatch):
+    monkeypatch.setenv('VV_CTW_SHAPE', str(shape))
     cin, cout = 128, 64
     rng = np.random.default_rng(B * 23 + act)
     x = _bf16_round(rng.standard_normal((B, 8, 8, 8, cin)).astype(np.float32))
