@@ -18,6 +18,8 @@
 //                chunk c+1 then fly under the last 4 MFMAs of chunk c; fragment reads are inline asm, one k-step ahead
 //   epilogue   : folded BN + activation, LDS transpose, 16-byte stores of whole channel rows (the 256 outputs of a
 //                workgroup are contiguous in y when the output side is 8)
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -251,6 +253,207 @@ __global__ __launch_bounds__(512, 1) void conv_direct_kernel(const __bf16 *__res
     }
 }
 
+__global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             void *__restrict__ y, int dout_log2, unsigned x_bytes, unsigned w_bytes,
+                                                             int act, int out_fp8) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lo = dout_log2, no = 1 << lo, li = lo + 1, n = 1 << li;
+
+    // XCD-aware order: consecutive boxes (same sample) run on one XCD and share its L2
+    const int nwg = gridDim.x;
+    int blk = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bxw = no >> 3, bxh = no >> 3, bxd = no >> 2;
+    const int bw = blk % bxw; blk /= bxw;
+    const int bh = blk % bxh; blk /= bxh;
+    const int bd = blk % bxd; const int b = blk / bxd;
+    const int od0 = bd * 4, oh0 = bh * 8, ow0 = bw * 8;
+
+    const u32x4 rsx = vv_make_rsrc(x, x_bytes), rsw = vv_make_rsrc(w, w_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // ---- producers
+    auto issue_x = [&](int q, int slot) {            // slot = 0..6: piece slot*8 + wave of phase q into tile[q & 1]
+        const int piece = slot * 8 + wave;
+        const int rl = piece * 8 + (lane >> 3);
+        const int zd = rl / 81, rem = rl - zd * 81, jh = rem / 9, jw = rem - jh * 9;
+        const int g = (lane & 7) ^ ((2 * jw) & 7);
+        const int id = 2 * (od0 + zd) + ((q >> 2) & 1) - 1, ih = 2 * (oh0 + jh) + ((q >> 1) & 1) - 1, iw = 2 * (ow0 + jw) + (q & 1) - 1;
+        const bool ok = q < 8 && rl < 405 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+        const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * CD_RB + g * 16 : 0xFFFFFFF0u;
+        const unsigned dst = piece < CD_PIECES ? lds0 + (q & 1) * CD_TILE + piece * 1024 : lds0 + CD_DUMMY;
+        vv_dma16(rsx, vo, dst);
+    };
+    auto issue_w = [&](int c) {                      // chunk c = q*8 + a into ring[c % 3]: rows 16*wave .. 16*wave+15
+        const int q = c >> 3, a = c & 7;
+        const int td = 2 * ((a >> 2) & 1) + ((q >> 2) & 1), th = 2 * ((a >> 1) & 1) + ((q >> 1) & 1), tw = 2 * (a & 1) + (q & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        const unsigned st = lds0 + CD_RING + (c % CD_NST) * CD_WST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned vo = c < 64 ? (unsigned)row * (64 * CD_RB) + t * CD_RB + g * 16 : 0xFFFFFFF0u;
+            vv_dma16(rsw, vo, st + (wave * 2 + i) * 1024);
+        }
+    };
+
+    // ---- prologue: phase 0 tile, weight chunks 0..2
+#pragma unroll 1
+    for (int s = 0; s < 7; ++s) issue_x(0, s);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- consumer addressing (LDS byte addresses).  lane = (r, kq): row r of a 16-row fragment, k quarter kq of a 32-deep
+    // k-step; a wave's 64 outputs are 4 cell tiles of two output h-rows (rows 2 ct, 2 ct + 1: +18 tile rows = +2304 B each),
+    // its 64 channels 4 tiles of 16 weight rows (+2048 B each).  Slot key of a tile row: (2 jw) & 7 -- conflict-free for
+    // every tap and every ds_read_b128 lane group in this fragment shape (scratch search over all keys a jw + b jh + c zd).
+    const int r = lane & 15, kq = lane >> 4;
+    const int rl0 = wm * 81 + (r >> 3) * 9 + (r & 7);
+    unsigned xo[2][2], wo[2];                      // [aw][k-step] inside tile 0 / [k-step] inside weight stage 0
+#pragma unroll
+    for (int aw = 0; aw < 2; ++aw)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xo[aw][ks] = lds0 + rl0 * CD_RB + (((ks * 4 + kq) ^ ((2 * ((r & 7) + aw)) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wo[ks] = lds0 + CD_RING + (wn * 64 + r) * 128 + (((ks * 4 + kq) ^ ((r >> 1) & 7)) << 4);
+
+    f32x4 acc[4][4];                               // [cot][ct]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define CD16_LD(F, XA, XOFF, WA)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %8 offset:%10\n\tds_read_b128 %1, %8 offset:%11\n\tds_read_b128 %2, %8 offset:%12\n\t"         \
+                 "ds_read_b128 %3, %8 offset:%13\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:2048\n\t"                   \
+                 "ds_read_b128 %6, %9 offset:4096\n\tds_read_b128 %7, %9 offset:6144"                                               \
+                 : "=&v"(F[0]), "=&v"(F[1]), "=&v"(F[2]), "=&v"(F[3]), "=&v"(F[4]), "=&v"(F[5]), "=&v"(F[6]), "=&v"(F[7])            \
+                 : "v"(XA), "v"(WA), "n"(XOFF), "n"((XOFF) + 2304), "n"((XOFF) + 4608), "n"((XOFF) + 6912)                          \
+                 : "memory")
+#define CD16_WAIT(F, N)                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                            \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])                    \
+                 : "n"(N)                                                                                                           \
+                 : "memory")
+#define CD16_MFMA(F)                                                                                                                \
+    do {                                                                                                                            \
+        _Pragma("unroll") for (int cot = 0; cot < 4; ++cot) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                        \
+            acc[cot][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + cot]),                  \
+                                                                   *reinterpret_cast<const bf16x8 *>(&F[ct]), acc[cot][ct], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    } while (0)
+
+    u32x4 P[8], Q[8];
+    CD16_LD(P, xo[0][0], 0, wo[0]);                // chunk 0, k-step 0
+
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        const unsigned tsel = (q & 1) * CD_TILE, tnext = ((q + 1) & 1) * CD_TILE;
+        auto tap = [&](auto a_c) {
+            constexpr int A = decltype(a_c)::value;
+            constexpr int AW = A & 1, TO = (((A >> 2) & 1) * 81 + ((A >> 1) & 1) * 9 + AW) * CD_RB;
+            constexpr int AN = (A + 1) & 7, AWN = AN & 1, TON = (((AN >> 2) & 1) * 81 + ((AN >> 1) & 1) * 9 + AWN) * CD_RB;
+            const int c = q * 8 + A;
+            const unsigned wsel = (c % CD_NST) * CD_WST, wnext = ((c + 1) % CD_NST) * CD_WST;
+            CD16_LD(Q, xo[AW][1] + tsel, TO, wo[1] + wsel);
+            CD16_WAIT(P, 8);
+            CD16_MFMA(P);
+            CD16_WAIT(Q, 0);                       // every LDS read of chunk c has returned: its stage may be refilled
+            // chunk c+1's weights (and, before tap 0 of the next phase, the whole next tile) have landed.  Pieces issued
+            // after w(c+1): [x piece of tap A-1] w(c+2) x2; tap 7 needs the x piece of tap 6, which precedes w(c+2).
+            wait_vm<(A == 0 || A == 7) ? 2 : 3>();
+            __syncthreads();
+            if (A < 7) issue_x(q + 1, A);
+            issue_w(c + 3);
+            CD16_LD(P, xo[AWN][0] + (A == 7 ? tnext : tsel), TON, wo[0] + wnext);
+            CD16_MFMA(Q);
+        };
+        tap(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 1>{});
+        tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{});
+        tap(std::integral_constant<int, 4>{});
+        tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{});
+        tap(std::integral_constant<int, 7>{});
+    }
+    CD16_WAIT(P, 0);                                // the look-ahead reads of the non-existent chunk 64
+    wait_vm<0>();                                   // trailing zero-fill pieces still target LDS
+    __syncthreads();
+
+    // ---- epilogue: lane = output (wm, mt, fr); registers walk channels
+    char *stage = smem;
+    // folded BN quads of this lane's 16 channels (wn*64 + 16 cot + 4 kq ..), fetched as one batch
+    f32x4 scv[4], shv[4];
+#pragma unroll
+    for (int cot = 0; cot < 4; ++cot) { scv[cot] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[cot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (scale) {
+#pragma unroll
+        for (int cot = 0; cot < 4; ++cot) scv[cot] = *reinterpret_cast<const f32x4 *>(scale + wn * 64 + cot * 16 + 4 * kq);
+    }
+    if (shift) {
+#pragma unroll
+        for (int cot = 0; cot < 4; ++cot) shv[cot] = *reinterpret_cast<const f32x4 *>(shift + wn * 64 + cot * 16 + 4 * kq);
+    }
+    auto fill = [&](auto act_c, auto fp8_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool FP8 = decltype(fp8_c)::value;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int cot = 0; cot < 4; ++cot) {
+                const int c = wn * 64 + cot * 16 + 4 * kq;
+                const f32x4 sc = scv[cot], sh = shv[cot];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[cot][ct][e] * sc[e] + sh[e];
+                    if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
+                    else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
+                    v[e] = t;
+                }
+                char *dst = stage + (wm * 64 + ct * 16 + r) * CD_SP;
+                if (FP8) {
+                    *reinterpret_cast<unsigned *>(dst + c) = vv_pack_fp8x4(v);
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
+                    *reinterpret_cast<bf16x4 *>(dst + c * 2) = o;
+                }
+            }
+    };
+    auto with_out = [&](auto act_c) {
+        if (out_fp8) fill(act_c, std::true_type{});
+        else fill(act_c, std::false_type{});
+    };
+    switch (act) {
+        case VV_ACT_ELU: with_out(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: with_out(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: with_out(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: with_out(std::integral_constant<int, VV_ACT_NONE>{}); break;
+    }
+    __syncthreads();
+    const int es = out_fp8 ? 1 : 2;                   // the fp8 form hands the layer's output to an fp8 consumer (e4m3fn)
+    const int cpr = CD_COUT * es / 16;                // 16-byte chunks per output row
+    for (int id = tid; id < 256 * cpr; id += 512) {
+        const int r = id / cpr, cc = id % cpr;
+        const int od = od0 + (r >> 6), oh = oh0 + ((r >> 3) & 7), ow = ow0 + (r & 7);
+        const size_t vox = ((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (CD_COUT * es) + cc * 16) =
+            *reinterpret_cast<const uint4 *>(stage + r * CD_SP + cc * 16);
+    }
+}
+
+
 }  // namespace
 
 VV_EXPORT int vv_conv3d_k4s2_direct_supported(int side, int cin, int cout, int dtype) {
@@ -269,12 +472,19 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
     const int boxes = (so / 4) * (so / 8) * (so / 8);
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
         return true;
     }();
     (void)attr;
-    VV_LAUNCH(conv_direct_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
-              reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
-              vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
+    const char *se = getenv("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    if (!se || atoi(se) != 32)
+        VV_LAUNCH(conv_direct16_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
+                  reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
+                  vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
+    else
+        VV_LAUNCH(conv_direct_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
+                  reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
+                  vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
     return vv_launch_status();
 }
 

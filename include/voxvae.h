@@ -157,8 +157,8 @@ int vv_convT3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *sca
 /* conv3DDec 8^3 x 128 -> 16^3 x 64 (autoencoder3D.py:41-54; the 32^3 model's widest decoder layer) with one WHOLE sample
  * resident in LDS per workgroup (128 KiB, no halo: out-of-grid taps read a zero row), all eight waves on the same output
  * parity sharing each weight chunk through an LDS ring (bf16 only).  w_skip = vv_pack_convT_k4s2_skip's image.  One
- * workgroup per (sample, parity split); the 8 parities are split over 2 / 4 / 8 workgroups when the batch alone would not
- * fill the chip (VV_CTW_PS overrides).  Replaces vv_convT3d_k4s2_direct_fwd at this shape; no workspace. */
+ * workgroup per (sample, parity split); the 8 parities are split over 2 / 4 / 8 workgroups until the grid holds two rounds
+ * of workgroups per CU (VV_CTW_PS overrides; VV_CTW_SHAPE=32 selects the 32x32x16 MFMA form, default 16x16x32).  Replaces vv_convT3d_k4s2_direct_fwd at this shape; no workspace. */
 int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype);
 int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
                               int side, int cin, int cout, int act, int dtype, void *stream);

@@ -438,8 +438,10 @@ def test_convT3d_k4s2_direct(L, B, side, variant, monkeypatch):
     _check(y, ref, 'bf16', 'convT3d_k4s2_direct')
 
 
+@pytest.mark.parametrize('shape', [16, 32])            # MFMA shape: 16x16x32 (default) / 32x32x16
 @pytest.mark.parametrize('B,side,act', [(2, 16, 1), (1, 32, 1), (3, 16, 0), (5, 16, 2)])
-def test_conv3d_k4s2_direct(L, B, side, act):
+def test_conv3d_k4s2_direct(L, B, side, act, shape, monkeypatch):
+    monkeypatch.setenv('VV_CD_SHAPE', str(shape))
     """LDS-resident phase-tile variant of the widest encoder layer (bf16, 64 -> 128); also bit-compared with the
     implicit-GEMM kernel's result on the same inputs (same bf16 operands, different summation order)."""
     cin, cout = 64, 128
