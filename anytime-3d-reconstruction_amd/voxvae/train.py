@@ -231,7 +231,14 @@ class Trainer:
         transposed layers (packed / packed_frag = the engine's images) and the data gradients of the strided convolutions."""
         dt, st = self.dt, _st()
         y = self._aempty(B, 2 * side, 2 * side, 2 * side, cout)
-        if L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT'):
+        if (L.load().vv_convT3d_k4s2_whole_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT')
+                and not os.environ.get('VV_NO_WHOLE')):
+            # 8^3 x 128 -> 16^3 x 64 (the widest decoder layer forward, and the data gradient of the widest encoder layer):
+            # whole-sample kernel; its weight image is packed here (the weights change every step)
+            wk = self._aempty(64 * cin * cout)
+            L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wk), cin, cout, st)
+            L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(x), L.ptr(wk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
+        elif L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT'):
             wf = packed_frag
             if wf is None:
                 wf = self._aempty(64 * cin * cout)
