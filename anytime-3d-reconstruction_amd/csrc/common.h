@@ -83,6 +83,32 @@ __device__ __forceinline__ float vv_apply_act_fast(float v, int act) {
     }
 }
 
+// Folded BN + activation of one accumulator quad (4 consecutive channels) for the bf16 epilogues: v * sc + sh, then the
+// activation.  ELU is written as max(t, 0) + (exp2(min(t, 0) * log2 e) - 1): the same value as `t > 0 ? t : __expf(t) - 1`
+// bit for bit (for t > 0 the second term is exp2(0) - 1 = 0 exactly), but every step except min / max / exp pairs up into
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 22 VALU instructions per quad instead of 26 (no compare + select).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int ACT>
+__device__ __forceinline__ f32x4 vv_bn_act4(f32x4 v, f32x4 sc, f32x4 sh) {
+    f32x2 t0 = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+    f32x2 t1 = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+    if (ACT == VV_ACT_ELU) {
+        const float L2E = 1.4426950408889634f;
+        const f32x2 m0 = f32x2{fminf(t0[0], 0.f), fminf(t0[1], 0.f)} * L2E, m1 = f32x2{fminf(t1[0], 0.f), fminf(t1[1], 0.f)} * L2E;
+        const f32x2 e0 = f32x2{__builtin_amdgcn_exp2f(m0[0]), __builtin_amdgcn_exp2f(m0[1])} - 1.f;
+        const f32x2 e1 = f32x2{__builtin_amdgcn_exp2f(m1[0]), __builtin_amdgcn_exp2f(m1[1])} - 1.f;
+        t0 = f32x2{fmaxf(t0[0], 0.f), fmaxf(t0[1], 0.f)} + e0;
+        t1 = f32x2{fmaxf(t1[0], 0.f), fmaxf(t1[1], 0.f)} + e1;
+    } else if (ACT == VV_ACT_RELU) {
+        t0 = f32x2{fmaxf(t0[0], 0.f), fmaxf(t0[1], 0.f)};
+        t1 = f32x2{fmaxf(t1[0], 0.f), fmaxf(t1[1], 0.f)};
+    } else if (ACT == VV_ACT_LRELU) {
+        t0 = f32x2{t0[0] > 0.f ? t0[0] : 0.3f * t0[0], t0[1] > 0.f ? t0[1] : 0.3f * t0[1]};
+        t1 = f32x2{t1[0] > 0.f ? t1[0] : 0.3f * t1[0], t1[1] > 0.f ? t1[1] : 0.3f * t1[1]};
+    }
+    return f32x4{t0[0], t0[1], t1[0], t1[1]};
+}
+
 // OCP e4m3fn storage (gfx950's fp8; not MI300's fnuz).  Conversions saturate at +-448 by hand: the hardware convert maps
 // larger magnitudes to NaN.
 struct vv_fp8 { unsigned char v; };

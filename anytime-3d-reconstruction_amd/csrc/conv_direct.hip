@@ -411,15 +411,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__r
             for (int cot = 0; cot < 4; ++cot) {
                 const int c = wn * 64 + cot * 16 + 4 * kq;
                 const f32x4 sc = scv[cot], sh = shv[cot];
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[cot][ct][e] * sc[e] + sh[e];
-                    if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
-                    else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
-                    else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                    v[e] = t;
-                }
+                const f32x4 v = vv_bn_act4<ACT>(acc[cot][ct], sc, sh);
                 char *dst = stage + (wm * 64 + ct * 16 + r) * CD_SP;
                 if (FP8) {
                     *reinterpret_cast<unsigned *>(dst + c) = vv_pack_fp8x4(v);

@@ -352,16 +352,11 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
                 const f32x4 sh = *reinterpret_cast<const f32x4 *>(ss + 256 + cot * 64);
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
+                    const f32x4 t = vv_bn_act4<ACT>(acc[cot][ct], sc, sh);
                     bf16x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[cot][ct][e] * sc[e] + sh[e];
-                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
-                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
-                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                        v[e] = static_cast<__bf16>(t);
-                        acc[cot][ct][e] = 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = static_cast<__bf16>(t[e]);
+                    acc[cot][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                     o[h][ct] = *reinterpret_cast<const u32x2 *>(&v);
                 }
             }

@@ -542,14 +542,20 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                                                                void *__restrict__ y, int batch, int din_log2, int act, int items_per_wg) {
     constexpr int COUT = 64, EPITCH = COUT * 2;            // output rows are 8 chunks of 16 B, chunk ^ (row & 7); fp8: 4 chunks, chunk ^ (row & 3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = act >> 8;                              // VV_FC_DBG timing ablations (wrong results): 1 no stores, 2 no BN/activation math, 4 no loads after the first item, 8 no MFMAs
+    act &= 255;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = din_log2, D = 1 << li, lo = li - 1, OW = 1 << lo;
     const int loh = 8 - lo, OH = 1 << loh;                 // output rows per item
     const int R = 2 * OH + 2, PD = (D >> 1) + 2, PP = R * PD;   // tile rows per plane, dwords per row / per plane
-    unsigned *tile = reinterpret_cast<unsigned *>(smem);   // [4][R][PD] dwords of bf16 pairs
-    char *stage = smem + ((4 * PP * 4 + 15) & ~15);        // [256][EPITCH]
-    float *ss = reinterpret_cast<float *>(stage + 256 * EPITCH);   // folded BN: scale[64], shift[64]
+    // bf16 output: the tile is double buffered and the outputs go from registers to memory (v_permlane32_swap pairs, 16-byte
+    // stores), so an item costs ONE barrier (tile published) -- the stage transpose, its barrier and its 32 KiB are the fp8
+    // output form's only (OUT8: [256][EPITCH] stage in place of the second tile buffer)
+    unsigned *tile0 = reinterpret_cast<unsigned *>(smem);  // [4][R][PD] dwords of bf16 pairs
+    const int tile_bytes = (4 * PP * 4 + 15) & ~15;
+    char *stage = smem + tile_bytes;                       // OUT8 only
+    float *ss = reinterpret_cast<float *>(smem + tile_bytes + (OUT8 ? 256 * EPITCH : tile_bytes));   // folded BN: scale[64], shift[64]
     uint4 *wl = reinterpret_cast<uint4 *>(ss + 128);       // weights as A fragments [ks][nt][lane]
     if (tid < 64) ss[tid] = scale ? scale[tid] : 1.f;
     else if (tid < 128) ss[tid] = shift ? shift[tid - 64] : 0.f;
@@ -597,7 +603,10 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
     if (item0 < item_end) fetch(item0);
     auto run = [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
+    int buf = 0;
     for (long item = item0; item < item_end; ++item) {
+        unsigned *tile = OUT8 ? tile0 : tile0 + buf * (tile_bytes >> 2);
+        buf ^= 1;
         // ---- planes -> LDS (bf16 pairs, left pad)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
             }
         }
         __syncthreads();
-        if (item + 1 < item_end) fetch(item + 1);
+        if (item + 1 < item_end && !(dbg & 4)) fetch(item + 1);
 
         // one 32-output row tile at a time (2 x 16 accumulator registers live): 8 MFMAs, then its epilogue
 #pragma unroll
@@ -629,10 +638,38 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const uint4 wf = wl[(ks * 2 + nt) * 64 + lane];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wf),
+                    if (!(dbg & 8)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wf),
                                                                       *reinterpret_cast<const bf16x8 *>(&xf), acc[nt], 0, 0, 0);
                 }
             }
+            if constexpr (!OUT8) {
+                // folded BN + activation; lanes fr / fr + 32 hold channels 8g + 0..3 / 8g + 4..7 of output o: swapping the upper
+                // half of quad 2j with the lower half of quad 2j + 1 gives every lane 8 consecutive channels (guide T21)
+                char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2) + o * (COUT * 2) + fh * 16;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    u32x2 oq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = nt * 32 + 8 * g + 4 * fh;
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
+                        f32x4 tv = f32x4{acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                        if (!(dbg & 2)) tv = vv_bn_act4<ACT>(tv, sc, sh);
+                        bf16x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = static_cast<__bf16>(tv[e]);
+                        oq[g] = *reinterpret_cast<const u32x2 *>(&ov);
+                    }
+                    if (!(dbg & 1)) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            auto rx = __builtin_amdgcn_permlane32_swap(oq[2 * j][0], oq[2 * j + 1][0], false, false);
+                            auto ry = __builtin_amdgcn_permlane32_swap(oq[2 * j][1], oq[2 * j + 1][1], false, false);
+                            *reinterpret_cast<u32x4 *>(yo + nt * 64 + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                        }
+                    }
+                }
+            } else
             // folded BN + activation, transpose through LDS
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -640,15 +677,8 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                 for (int g = 0; g < 4; ++g) {
                     const int c = nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
-                    f32x4 tv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = acc[nt][4 * g + e] * sc[e] + sh[e];
-                        if (ACT == VV_ACT_ELU) { const float em = __expf(fminf(t, 0.f)) - 1.f; t = t > 0.f ? t : em; }
-                        else if (ACT == VV_ACT_RELU) t = fmaxf(t, 0.f);
-                        else if (ACT == VV_ACT_LRELU) t = t > 0.f ? t : 0.3f * t;
-                        tv[e] = t;
-                    }
+                    f32x4 tv = f32x4{acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+                    if (!(dbg & 2)) tv = vv_bn_act4<ACT>(tv, sc, sh);
                     if constexpr (OUT8) {                  // e4m3fn for an fp8 second layer: 64-byte rows
                         *reinterpret_cast<unsigned *>(stage + o * EPITCH + ((((c >> 4) ^ o) & 3) << 4) + (c & 12)) = vv_pack_fp8x4(tv);
                     } else {
@@ -659,20 +689,13 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                     }
                 }
         }
-        __syncthreads();
         if constexpr (OUT8) {
+            __syncthreads();
             char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i, rl = idx >> 2, c = idx & 3;
                 *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 3) << 4));
-            }
-        } else {
-            char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2);     // the item's 256 outputs are contiguous in y
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * i, rl = idx >> 3, c = idx & 7;
-                *reinterpret_cast<uint4 *>(yo + (size_t)idx * 16) = *reinterpret_cast<const uint4 *>(stage + rl * EPITCH + (((c ^ rl) & 7) << 4));
             }
         }
     }
@@ -827,13 +850,17 @@ int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float 
     if (side >= 32 && side <= 256 && (out_fp8 || !getenv("VV_FIRSTCONV_GATHER"))) {
         const int ow = side / 2, oh = 256 / ow, r = 2 * oh + 2, pd = side / 2 + 2;
         const long nitems = (long)batch * ow * (ow / oh);
-        const size_t lds = (((size_t)4 * r * pd * 4 + 15) & ~(size_t)15) + 256 * (64 * 2) + 128 * sizeof(float) + 8 * 64 * 16;
+        const size_t tile_b = ((size_t)4 * r * pd * 4 + 15) & ~(size_t)15;
+        const size_t lds = tile_b + (out_fp8 ? (size_t)256 * (64 * 2) : tile_b) + 128 * sizeof(float) + 8 * 64 * 16;
         const int nslots = 4 * r * (side / 4), ni = (nslots + 255) / 256;
-        static const long maxwg = getenv("VV_FIRSTCONV_WGS") ? atol(getenv("VV_FIRSTCONV_WGS")) : 256 * 3;
+        // persistent workgroups: what fits a CU at once -- 4 for the bf16-output form at D = 32 (128 VGPRs, 28 KB of LDS), else 3
+        static const long envwg = getenv("VV_FIRSTCONV_WGS") ? atol(getenv("VV_FIRSTCONV_WGS")) : 0;
+        const long maxwg = envwg > 0 ? envwg : 256 * ((out_fp8 || ni > 5) ? 3 : 4);
         const int ipw = (int)((nitems + maxwg - 1) / maxwg);
         const int grid = (int)((nitems + ipw - 1) / ipw);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
+        if (const char *de = getenv("VV_FC_DBG")) act |= atoi(de) << 8;
         if (ni <= 5) {
             if (out_fp8) VV_LAUNCH((first_conv_plane_kernel<5, true>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
             else VV_LAUNCH((first_conv_plane_kernel<5, false>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
