@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024 + 24 * 128);   // P_d[td 0,1]      [100][36]
     float *PH = PL + SW_PSZ;                                     // P_d / P_{d-1}[td 2,3]  [2][100][33]
     __shared__ float red[4][4];
-    const int li = din_log2, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
+    const int dbg = din_log2 >> 8;      // VV_SW_DBG timing ablations (wrong results): 1 no stores, 2 no loss math, 4 no gather, 8 no MFMAs, 16 no P publish, 32 no plane DMA after the first two
+    const int li = din_log2 & 255, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
     const int T = gridDim.x;
     const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
     const int tile = wi % ntile, b = wi / ntile;
@@ -285,17 +286,29 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     // vector-memory counter advances uniformly); rows >= 100, voxels outside the grid and planes outside [0, n) arrive
     // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
     // the slot: whatever it finds there only reaches accumulator rows >= 104, which are never published.
-    auto stage = [&](int d) {
+    // The lane part of a piece's source offset (sample, halo row, swizzled slot; out-of-range if the row is outside the grid
+    // or past the 100 halo rows) is prepared once; the plane rides in soffset, and a plane outside [0, n) is fetched through a
+    // descriptor of zero records (every lane out of range -> zeros).
+    unsigned sv[4], sdst[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
-            const int zh = row / 10, zw = row - zh * 10;
-            const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
-            const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
-            const int g = (lane & 7) ^ ((row >> 1) & 7);
-            const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
-            vv_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
+        const int zh = row / 10, zw = row - zh * 10;
+        const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+        const bool ok = row < SW_ROWS && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+        const int g = (lane & 7) ^ ((row >> 1) & 7);
+        sv[i] = ok ? (unsigned)(((((b << li) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
+        sdst[i] = piece < 13 ? (unsigned)(piece * 1024) : (unsigned)(SW_NX * SW_XB);     // surplus pieces: the sink (ring-slot independent)
+    }
+    u32x4 rs_none = rs;
+    rs_none[2] = 0u;
+    auto stage = [&](int d) {
+        const bool din = (unsigned)d < (unsigned)n && !((dbg & 32) && d > 1);
+        const u32x4 r = din ? rs : rs_none;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
+        const unsigned slot = ldsx + (d % SW_NX) * SW_XB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv_dma16(r, sv[i], soff, wv * 4 + i < 13 ? slot + sdst[i] : ldsx + sdst[i]);
     };
     stage(0);
 
@@ -327,14 +340,18 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     auto mfma_plane = [&](int d, f32x16 (&acc)[2]) {
         const char *Xd = Xs + (d % SW_NX) * SW_XB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-            const int mt = mt0 + 2 * j;
+        // k-step outer, row tile inner: consecutive MFMAs go to different accumulators (the other order is two chains of four
+        // dependent MFMAs)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int mt = mt0 + 2 * j;
                 const uint4 fa = *reinterpret_cast<const uint4 *>(Xd + fm_lds_off(mt * 32 + fr, ks * 2 + fh));
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
+                if (!(dbg & 8)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
                                                                  *reinterpret_cast<const bf16x8 *>(&fa), acc[j], 0, 0, 0);
             }
         }
@@ -347,17 +364,24 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     f32x16 acc[2];
     mfma_plane(0, acc);
     stage(1);
+    float2 ya, yb;                                               // target pairs of this / the next step (roles alternate)
+    {
+        const size_t o0 = (((((size_t)b << lo) + 0) << lo) + oh << lo) + ow;   // step 0: od = -1 + sl (plane 0 for sl = 1; unused for sl = 0)
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ya) : "v"(target + o0) : "memory");
+    }
     __syncthreads();                                             // slot 0 may be refilled (plane 2) from the first step on
 
-#pragma unroll 1
-    for (int d = 0; d <= n; ++d) {
+    // one step; y = this step's target pair (landed by the wait below), ynext = the register pair the next step's lands in.
+    // The two swap roles every step (the loop is unrolled by two): a register copy of a pair that is still in flight would read
+    // the old contents.
+    auto sweep_step = [&](int d, float2 &y, float2 &ynext) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
         // of one (td, th): one 16-byte store per quad
         float *Pw = nt == 0 ? PL : PH + (oldh ^ 1) * SW_PSZ;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (mt0 + 2 * j) * 32 + fr;
-            if (row < SW_ROWS) {
+            if (row < SW_ROWS && !(dbg & 16)) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<f32x4 *>(Pw + row * SW_PP + 8 * g + 4 * fh) =
@@ -367,15 +391,21 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         const int od = 2 * d - 1 + sl;
         const bool ovalid = (unsigned)od < (unsigned)n2;
         const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
-        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
-        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
-        // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
-        //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
-        // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
-        float2 y;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
+        // The target pair of the NEXT step is loaded here, by inline asm so that its wait can be counted (a compiler-placed wait
+        // would be vmcnt(0), i.e. it would also wait for the pieces of plane d+2 issued right after it -- the look-ahead): this
+        // step's pair was issued a step ago and has had a whole step to arrive (loaded in the step that uses it, its ~1 us of
+        // HBM latency sat on the critical path of every one of the 17 steps: 0.03 ms of the launch, VV_SW_DBG ablations).
+        // The vector-memory counter retires in order; in flight, oldest first:
+        //   [y d][plane d+1 x4][stores d-1] [y d+1][plane d+2 x4]
+        // so "all but the newest 5" covers y d and plane d+1 whatever the number of stores (more stores only wait for more).
+        // (Two steps ahead, three rotating pairs: no further gain, 67 vs 65 us.)
+        {
+            const int odn = od + 2;
+            const size_t on = ((((((size_t)b << lo) + ((unsigned)odn < (unsigned)n2 ? odn : 0)) << lo) + oh) << lo) + ow;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ynext) : "v"(target + on) : "memory");
+        }
         stage(d + 2);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d+1 (issued a step ago) has landed
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(y) : : "memory");   // y d and plane d+1 (issued a step ago) have landed
         __syncthreads();                                         // ... for every wave; P_d is published
 
         f32x16 acc_next[2];
@@ -383,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
 
         float l0 = 0.f, l1 = 0.f;
         const float *Pold = PH + oldh * SW_PSZ;
+        if (!(dbg & 4))
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah) {
             const int zh = mh + ph - ah + 1, th = 1 - ph + 2 * ah;
@@ -391,10 +422,10 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             l0 += r0[SW_PP + 1] + r0[3] + r1[SW_PP + 1] + r1[3];                         // pw = 0
             l1 += r0[2 * SW_PP] + r0[SW_PP + 2] + r1[2 * SW_PP] + r1[SW_PP + 2];   // pw = 1
         }
-        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
         if (ovalid) {
             const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
-            float p[2];
+            float p[2] = {l0, l1};
+            if (!(dbg & 2))
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 p[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-l[e]));
@@ -403,14 +434,21 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
                 const float yh = l[e] >= 0.f ? 1.f : 0.f;
                 tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
             }
-            if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
-            if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+            if (probs && !(dbg & 1)) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+            if (logits && !(dbg & 1)) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
         }
         acc[0] = acc_next[0];
         acc[1] = acc_next[1];
         oldh ^= 1;
         __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
+    };
+    int d = 0;
+#pragma unroll 1
+    for (; d + 1 <= n; d += 2) {
+        sweep_step(d, ya, yb);
+        sweep_step(d + 1, yb, ya);
     }
+    if (d <= n) sweep_step(d, ya, yb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
     bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
     if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
@@ -825,8 +863,10 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
             return true;
         }();
         (void)attr;
+        const char *swd = getenv("VV_SW_DBG");
+        const int swdbg = swd ? atoi(swd) << 8 : 0;
         VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * batch), dim3(256), SW_LDS, st, reinterpret_cast<const __bf16 *>(x), w_keras, target,
-                  probs, logits, partials, vv_log2(side), (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
+                  probs, logits, partials, vv_log2(side) | swdbg, (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
         finish_stats(partials, stats, metrics4, ntile, batch, st);
         return vv_launch_status();
     }
