@@ -287,8 +287,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
     // the slot: whatever it finds there only reaches accumulator rows >= 104, which are never published.
     // The lane part of a piece's source offset (sample, halo row, swizzled slot; out-of-range if the row is outside the grid
-    // or past the 100 halo rows) is prepared once; the plane rides in soffset, and a plane outside [0, n) is fetched through a
-    // descriptor of zero records (every lane out of range -> zeros).
+    // or past the 100 halo rows) is prepared once; the plane rides in soffset.
     unsigned sv[4], sdst[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -300,15 +299,15 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         sv[i] = ok ? (unsigned)(((((b << li) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
         sdst[i] = piece < 13 ? (unsigned)(piece * 1024) : (unsigned)(SW_NX * SW_XB);     // surplus pieces: the sink (ring-slot independent)
     }
-    u32x4 rs_none = rs;
-    rs_none[2] = 0u;
     auto stage = [&](int d) {
+        // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
+        // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
+        // B = 256 cross-check against the box form, scratch/chk_e1_d5.py.)
         const bool din = (unsigned)d < (unsigned)n && !((dbg & 32) && d > 1);
-        const u32x4 r = din ? rs : rs_none;
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
         const unsigned slot = ldsx + (d % SW_NX) * SW_XB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vv_dma16(r, sv[i], soff, wv * 4 + i < 13 ? slot + sdst[i] : ldsx + sdst[i]);
+        for (int i = 0; i < 4; ++i) vv_dma16(rs, din ? sv[i] : 0xFFFFFFF0u, soff, wv * 4 + i < 13 ? slot + sdst[i] : ldsx + sdst[i]);
     };
     stage(0);
 
@@ -364,17 +363,10 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     f32x16 acc[2];
     mfma_plane(0, acc);
     stage(1);
-    float2 ya, yb;                                               // target pairs of this / the next step (roles alternate)
-    {
-        const size_t o0 = (((((size_t)b << lo) + 0) << lo) + oh << lo) + ow;   // step 0: od = -1 + sl (plane 0 for sl = 1; unused for sl = 0)
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ya) : "v"(target + o0) : "memory");
-    }
     __syncthreads();                                             // slot 0 may be refilled (plane 2) from the first step on
 
-    // one step; y = this step's target pair (landed by the wait below), ynext = the register pair the next step's lands in.
-    // The two swap roles every step (the loop is unrolled by two): a register copy of a pair that is still in flight would read
-    // the old contents.
-    auto sweep_step = [&](int d, float2 &y, float2 &ynext) {
+#pragma unroll 1
+    for (int d = 0; d <= n; ++d) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
         // of one (td, th): one 16-byte store per quad
         float *Pw = nt == 0 ? PL : PH + (oldh ^ 1) * SW_PSZ;
@@ -391,21 +383,17 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         const int od = 2 * d - 1 + sl;
         const bool ovalid = (unsigned)od < (unsigned)n2;
         const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
-        // The target pair of the NEXT step is loaded here, by inline asm so that its wait can be counted (a compiler-placed wait
-        // would be vmcnt(0), i.e. it would also wait for the pieces of plane d+2 issued right after it -- the look-ahead): this
-        // step's pair was issued a step ago and has had a whole step to arrive (loaded in the step that uses it, its ~1 us of
-        // HBM latency sat on the critical path of every one of the 17 steps: 0.03 ms of the launch, VV_SW_DBG ablations).
-        // The vector-memory counter retires in order; in flight, oldest first:
-        //   [y d][plane d+1 x4][stores d-1] [y d+1][plane d+2 x4]
-        // so "all but the newest 5" covers y d and plane d+1 whatever the number of stores (more stores only wait for more).
-        // (Two steps ahead, three rotating pairs: no further gain, 67 vs 65 us.)
-        {
-            const int odn = od + 2;
-            const size_t on = ((((((size_t)b << lo) + ((unsigned)odn < (unsigned)n2 ? odn : 0)) << lo) + oh) << lo) + ow;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ynext) : "v"(target + on) : "memory");
-        }
+        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
+        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
+        // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
+        //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
+        // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
+        // (Fetching the pair a step ahead -- into registers by a second asm load, or into LDS by DMA -- is a measured dead
+        // end, DESIGN.md section 4d: the compiler copies / re-uses the registers of a load it believes complete.)
+        float2 y;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
         stage(d + 2);
-        asm volatile("s_waitcnt vmcnt(5)" : "+v"(y) : : "memory");   // y d and plane d+1 (issued a step ago) have landed
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d+1 (issued a step ago) has landed
         __syncthreads();                                         // ... for every wave; P_d is published
 
         f32x16 acc_next[2];
@@ -422,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             l0 += r0[SW_PP + 1] + r0[3] + r1[SW_PP + 1] + r1[3];                         // pw = 0
             l1 += r0[2 * SW_PP] + r0[SW_PP + 2] + r1[2 * SW_PP] + r1[SW_PP + 2];   // pw = 1
         }
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
         if (ovalid) {
             const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
             float p[2] = {l0, l1};
@@ -441,14 +430,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         acc[1] = acc_next[1];
         oldh ^= 1;
         __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
-    };
-    int d = 0;
-#pragma unroll 1
-    for (; d + 1 <= n; d += 2) {
-        sweep_step(d, ya, yb);
-        sweep_step(d + 1, yb, ya);
     }
-    if (d <= n) sweep_step(d, ya, yb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
     bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
     if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }

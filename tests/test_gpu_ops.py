@@ -656,6 +656,60 @@ def _check_fp8_out(got_f8, ref, what):
     assert not bad.any(), '%s: %d of %d beyond fp8 rounding, worst %.3e' % (what, bad.sum(), bad.size, np.abs(got - ref).max())
 
 
+def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
+    """B = 256 (BASELINE configs[1]: several items / steps per persistent workgroup, two workgroups per CU): the plane form of the
+    first layer equals its gather form bit for bit, and the depth-sweep form of the last layer equals the 4^3-box form (logits to
+    1e-5, loss sums to float32 summation error) and the float64 definition of the four loss sums -- run twice (a race in a
+    look-ahead load showed up only here: wrong logits in the last output plane, different from run to run)."""
+    B = 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.rand(B, 32, 32, 32, 1, device=DEV, generator=g) < 0.1).float().contiguous()
+    w = (torch.randn(4, 4, 4, 1, 64, device=DEV, generator=g) / 8).contiguous()
+    sc = torch.rand(64, device=DEV, generator=g) + 0.5
+    sh = torch.randn(64, device=DEV, generator=g) * 0.3
+    wp = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(w), L.ptr(wp), 1, 64, L.VV_BF16, _st())
+
+    def e1():
+        y = torch.full((B, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 32, 64, 1, L.VV_BF16, _st())
+        torch.cuda.synchronize()
+        return y
+    y0, y1 = e1(), e1()
+    monkeypatch.setenv('VV_FIRSTCONV_GATHER', '1')
+    yg = e1()
+    monkeypatch.delenv('VV_FIRSTCONV_GATHER')
+    assert torch.equal(y0, yg) and torch.equal(y1, yg)
+
+    xa = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=g).to(torch.bfloat16)
+    w5 = (torch.randn(4, 4, 4, 1, 64, device=DEV, generator=g) / 16).contiguous()
+    tgt = (torch.rand(B, 32, 32, 32, 1, device=DEV, generator=g) < 0.1).float().contiguous()
+    ws = torch.empty(max(L.load().vv_convT3d_final_bce_workspace_bytes(B, 16), 16), dtype=torch.uint8, device=DEV)
+
+    def d5():
+        lg = torch.full((B, 32, 32, 32, 1), float('nan'), device=DEV)
+        pr = torch.empty_like(lg)
+        st = torch.empty(B, 4, device=DEV)
+        L.call('vv_convT3d_final_bce_fwd', L.ptr(xa), L.ptr(w5), L.ptr(tgt), L.ptr(pr), L.ptr(lg), L.ptr(st), B, 16, 64, 0.6, 1e-7, L.VV_BF16,
+               L.ptr(ws), ws.numel(), _st())
+        torch.cuda.synchronize()
+        return lg, st
+    runs = [d5(), d5()]
+    monkeypatch.setenv('VV_FINAL_BCE', 'box')
+    lb, sb = d5()
+    monkeypatch.delenv('VV_FINAL_BCE')
+    l64, t64 = lb.double().view(B, -1), tgt.double().view(B, -1)
+    q = torch.sigmoid(l64).clamp(1e-7, 1 - 1e-7)
+    yh = (l64 >= 0).double()
+    ref = torch.stack([-(0.6 * t64 * q.log() + 0.4 * (1 - t64) * (1 - q).log()).sum(1), (t64 * yh).sum(1), ((1 - t64) * yh).sum(1),
+                       (t64 * (1 - yh)).sum(1)], 1)
+    for lg, st in runs:
+        assert (lg - lb).abs().max().item() <= 1e-5
+        assert torch.equal(lg, runs[0][0])
+        d = (st.double() - ref).abs().max(0).values
+        assert d[0].item() <= 1e-2 and d[1:].max().item() == 0.0, d.tolist()     # loss sum ~2e4 per sample; the counts are exact
+
+
 @pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
 @pytest.mark.parametrize('B,side,cin,cout,odt', [(2, 8, 128, 256, 'bf16'), (2, 8, 128, 256, 'fp8'), (37, 4, 256, 512, 'fp8'), (1, 16, 128, 64, 'f32'),
                                                  (2, 16, 64, 128, 'fp8'), (3, 8, 64, 128, 'bf16'), (33, 4, 64, 64, 'fp8')])   # Cin 64: tap-pair rows
