@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024 + 24 * 128);   // P_d[td 0,1]      [100][36]
     float *PH = PL + SW_PSZ;                                     // P_d / P_{d-1}[td 2,3]  [2][100][33]
     __shared__ float red[4][4];
-    const int dbg = din_log2 >> 8;      // VV_SW_DBG timing ablations (wrong results): 1 no stores, 2 no loss math, 4 no gather, 8 no MFMAs, 16 no P publish, 32 no plane DMA after the first two
+    const int dbg = din_log2 >> 8;      // VV_SW_DBG timing ablations (wrong results): 1 no stores, 2 no loss math, 4 no gather, 8 no MFMAs, 16 no P publish, 32 no plane DMA after the first two; 64 = per-call stage address math (A/B, correct results)
     const int li = din_log2 & 255, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
     const int T = gridDim.x;
     const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
@@ -303,6 +303,19 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
         // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
         // B = 256 cross-check against the box form, scratch/chk_e1_d5.py.)
+        if (dbg & 64) {                              // A/B: the per-call address arithmetic this replaced
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
+                const int zh = row / 10, zw = row - zh * 10;
+                const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+                const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+                const int g = (lane & 7) ^ ((row >> 1) & 7);
+                const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
+                vv_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
+            }
+            return;
+        }
         const bool din = (unsigned)d < (unsigned)n && !((dbg & 32) && d > 1);
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
         const unsigned slot = ldsx + (d % SW_NX) * SW_XB;
