@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         sv[i] = ok ? (unsigned)(((((b << li) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
         sdst[i] = piece < 13 ? (unsigned)(piece * 1024) : (unsigned)(SW_NX * SW_XB);     // surplus pieces: the sink (ring-slot independent)
     }
-    auto stage = [&](int d) {
+    auto stage = [&](int d, int sp) {              // sp = d % SW_NX, passed so that the unrolled steps see a constant
         // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
         // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
         // B = 256 cross-check against the box form, scratch/chk_e1_d5.py.)
@@ -312,17 +312,17 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
                 const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
                 const int g = (lane & 7) ^ ((row >> 1) & 7);
                 const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
-                vv_dma16(rs, vo, piece < 13 ? ldsx + (d % SW_NX) * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
+                vv_dma16(rs, vo, piece < 13 ? ldsx + sp * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
             }
             return;
         }
         const bool din = (unsigned)d < (unsigned)n && !((dbg & 32) && d > 1);
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
-        const unsigned slot = ldsx + (d % SW_NX) * SW_XB;
+        const unsigned slot = ldsx + sp * SW_XB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) vv_dma16(rs, din ? sv[i] : 0xFFFFFFF0u, soff, wv * 4 + i < 13 ? slot + sdst[i] : ldsx + sdst[i]);
     };
-    stage(0);
+    stage(0, 0);
 
     // weights of this wave's tap half as B fragments (lane: tap nt*32 + fr, k = ks*16 + 8 fh + j), straight from the
     // Keras array [64 taps][64 ci]
@@ -346,11 +346,10 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     const int oh = 2 * h0 + ohh, ow = 2 * (w0 + mw);
     const float hi = 1.0f - epsilon;
     float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
-    int oldh = 0;
 
     // P_d = X_d W^T for this wave's two row tiles and its tap half: D[tap][cell], weights-first
-    auto mfma_plane = [&](int d, f32x16 (&acc)[2]) {
-        const char *Xd = Xs + (d % SW_NX) * SW_XB;
+    auto mfma_plane = [&](int sp, f32x16 (&acc)[2]) {             // sp = ring slot of the plane
+        const char *Xd = Xs + sp * SW_XB;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -375,9 +374,13 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     __syncthreads();                                             // ... and the zeroed P_{-1}, for every wave
     f32x16 acc[2];
     mfma_plane(0, acc);
-    stage(1);
+    stage(1, 1);
     __syncthreads();                                             // slot 0 may be refilled (plane 2) from the first step on
 
+    // (Unrolling this loop by two with the step parity as a compile-time constant -- ring slot and P buffer addresses folded
+    // into the instructions -- ran in 62 us instead of 79 and returned a wrong loss sum at B = 256 with exact logits and counts;
+    // like the look-ahead target loads above it is not understood and not used.)
+    int oldh = 0;
 #pragma unroll 1
     for (int d = 0; d <= n; ++d) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
@@ -405,12 +408,12 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         // end, DESIGN.md section 4d: the compiler copies / re-uses the registers of a load it believes complete.)
         float2 y;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
-        stage(d + 2);
+        stage(d + 2, oldh);
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d+1 (issued a step ago) has landed
         __syncthreads();                                         // ... for every wave; P_d is published
 
         f32x16 acc_next[2];
-        mfma_plane(d + 1, acc_next);
+        mfma_plane(oldh ^ 1, acc_next);
 
         float l0 = 0.f, l1 = 0.f;
         const float *Pold = PH + oldh * SW_PSZ;
