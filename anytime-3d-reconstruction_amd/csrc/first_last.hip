@@ -270,8 +270,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024 + 24 * 128);   // P_d[td 0,1]      [100][36]
     float *PH = PL + SW_PSZ;                                     // P_d / P_{d-1}[td 2,3]  [2][100][33]
     __shared__ float red[4][4];
-    const int dbg = din_log2 >> 8;      // VV_SW_DBG timing ablations (wrong results): 1 no stores, 2 no loss math, 4 no gather, 8 no MFMAs, 16 no P publish, 32 no plane DMA after the first two; 64 = per-call stage address math (A/B, correct results)
-    const int li = din_log2 & 255, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
+    const int li = din_log2, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
     const int T = gridDim.x;
     const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
     const int tile = wi % ntile, b = wi / ntile;
@@ -303,20 +302,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
         // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
         // B = 256 cross-check against the box form, scratch/chk_e1_d5.py.)
-        if (dbg & 64) {                              // A/B: the per-call address arithmetic this replaced
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
-                const int zh = row / 10, zw = row - zh * 10;
-                const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
-                const bool ok = row < SW_ROWS && (unsigned)d < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
-                const int g = (lane & 7) ^ ((row >> 1) & 7);
-                const unsigned vo = ok ? (unsigned)((((((b << li) + d) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
-                vv_dma16(rs, vo, piece < 13 ? ldsx + sp * SW_XB + piece * 1024 : ldsx + SW_NX * SW_XB);
-            }
-            return;
-        }
-        const bool din = (unsigned)d < (unsigned)n && !((dbg & 32) && d > 1);
+        const bool din = (unsigned)d < (unsigned)n;
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
         const unsigned slot = ldsx + sp * SW_XB;
 #pragma unroll
@@ -362,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
             for (int j = 0; j < 2; ++j) {
                 const int mt = mt0 + 2 * j;
                 const uint4 fa = *reinterpret_cast<const uint4 *>(Xd + fm_lds_off(mt * 32 + fr, ks * 2 + fh));
-                if (!(dbg & 8)) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&fb[ks]),
                                                                  *reinterpret_cast<const bf16x8 *>(&fa), acc[j], 0, 0, 0);
             }
         }
@@ -389,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (mt0 + 2 * j) * 32 + fr;
-            if (row < SW_ROWS && !(dbg & 16)) {
+            if (row < SW_ROWS) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<f32x4 *>(Pw + row * SW_PP + 8 * g + 4 * fh) =
@@ -417,7 +403,6 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
 
         float l0 = 0.f, l1 = 0.f;
         const float *Pold = PH + oldh * SW_PSZ;
-        if (!(dbg & 4))
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah) {
             const int zh = mh + ph - ah + 1, th = 1 - ph + 2 * ah;
@@ -429,8 +414,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
         if (ovalid) {
             const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
-            float p[2] = {l0, l1};
-            if (!(dbg & 2))
+            float p[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 p[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-l[e]));
@@ -439,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
                 const float yh = l[e] >= 0.f ? 1.f : 0.f;
                 tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
             }
-            if (probs && !(dbg & 1)) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
-            if (logits && !(dbg & 1)) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+            if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+            if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
         }
         acc[0] = acc_next[0];
         acc[1] = acc_next[1];
@@ -578,8 +562,6 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                                                                void *__restrict__ y, int batch, int din_log2, int act, int items_per_wg) {
     constexpr int COUT = 64, EPITCH = COUT * 2;            // output rows are 8 chunks of 16 B, chunk ^ (row & 7); fp8: 4 chunks, chunk ^ (row & 3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = act >> 8;                              // VV_FC_DBG timing ablations (wrong results): 1 no stores, 2 no BN/activation math, 4 no loads after the first item, 8 no MFMAs
-    act &= 255;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = din_log2, D = 1 << li, lo = li - 1, OW = 1 << lo;
@@ -655,7 +637,7 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
             }
         }
         __syncthreads();
-        if (item + 1 < item_end && !(dbg & 4)) fetch(item + 1);
+        if (item + 1 < item_end) fetch(item + 1);
 
         // one 32-output row tile at a time (2 x 16 accumulator registers live): 8 MFMAs, then its epilogue
 #pragma unroll
@@ -674,7 +656,7 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const uint4 wf = wl[(ks * 2 + nt) * 64 + lane];
-                    if (!(dbg & 8)) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wf),
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wf),
                                                                       *reinterpret_cast<const bf16x8 *>(&xf), acc[nt], 0, 0, 0);
                 }
             }
@@ -690,19 +672,17 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                         const int c = nt * 32 + 8 * g + 4 * fh;
                         const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
                         f32x4 tv = f32x4{acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
-                        if (!(dbg & 2)) tv = vv_bn_act4<ACT>(tv, sc, sh);
+                        tv = vv_bn_act4<ACT>(tv, sc, sh);
                         bf16x4 ov;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = static_cast<__bf16>(tv[e]);
                         oq[g] = *reinterpret_cast<const u32x2 *>(&ov);
                     }
-                    if (!(dbg & 1)) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            auto rx = __builtin_amdgcn_permlane32_swap(oq[2 * j][0], oq[2 * j + 1][0], false, false);
-                            auto ry = __builtin_amdgcn_permlane32_swap(oq[2 * j][1], oq[2 * j + 1][1], false, false);
-                            *reinterpret_cast<u32x4 *>(yo + nt * 64 + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        auto rx = __builtin_amdgcn_permlane32_swap(oq[2 * j][0], oq[2 * j + 1][0], false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(oq[2 * j][1], oq[2 * j + 1][1], false, false);
+                        *reinterpret_cast<u32x4 *>(yo + nt * 64 + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
                     }
                 }
             } else
@@ -714,7 +694,7 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
                     const int c = nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
                     f32x4 tv = f32x4{acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
-                    if (!(dbg & 2)) tv = vv_bn_act4<ACT>(tv, sc, sh);
+                    tv = vv_bn_act4<ACT>(tv, sc, sh);
                     if constexpr (OUT8) {                  // e4m3fn for an fp8 second layer: 64-byte rows
                         *reinterpret_cast<unsigned *>(stage + o * EPITCH + ((((c >> 4) ^ o) & 3) << 4) + (c & 12)) = vv_pack_fp8x4(tv);
                     } else {
@@ -861,10 +841,8 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
             return true;
         }();
         (void)attr;
-        const char *swd = getenv("VV_SW_DBG");
-        const int swdbg = swd ? atoi(swd) << 8 : 0;
         VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * batch), dim3(256), SW_LDS, st, reinterpret_cast<const __bf16 *>(x), w_keras, target,
-                  probs, logits, partials, vv_log2(side) | swdbg, (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
+                  probs, logits, partials, vv_log2(side), (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
         finish_stats(partials, stats, metrics4, ntile, batch, st);
         return vv_launch_status();
     }
@@ -898,7 +876,6 @@ int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float 
         const int grid = (int)((nitems + ipw - 1) / ipw);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const __bf16 *wb = reinterpret_cast<const __bf16 *>(w_packed);
-        if (const char *de = getenv("VV_FC_DBG")) act |= atoi(de) << 8;
         if (ni <= 5) {
             if (out_fp8) VV_LAUNCH((first_conv_plane_kernel<5, true>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
             else VV_LAUNCH((first_conv_plane_kernel<5, false>), dim3(grid), dim3(256), lds, st, x, wb, scale, shift, y, batch, li, act, ipw);
