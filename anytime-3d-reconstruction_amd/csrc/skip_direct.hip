@@ -57,8 +57,6 @@ struct SdArgs {
     int batch, cin, cout, act;
     unsigned x_bytes, w_bytes;
     int groups;                            // workgroups per sample quad
-    int dbg;                               // timing ablations (VV_SD_DBG): 1 = no weight DMA after the ring is primed, 2 = no A DMA after the
-                                           // first two tiles, 4 = no MFMAs -- wrong results, diagnostics only
 };
 
 // out[((t*NC + c)*cout + n)*64 + k] = w[(t*cin + c*64 + k)*cout + n]          (Keras Conv3D [kd,kh,kw,Cin,Cout])
@@ -264,7 +262,6 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
                 xb1[i] = qw ? (okp1 ? lp1 + sc_ : zp1) : l00 + sc_;
             }
             dm0 = tile_mask(td_, qd - 1); dm1 = tile_mask(td_, qd); hm0 = tile_mask(th_, qh - 1); hm1 = tile_mask(th_, qh);
-            if (a.dbg & 4) dm0 = dm1 = 0;
         };
         // step j = (ah, aw) of unit AD: x fragments at immediate AD*2048 + ah*512, weight tiles at AD*32768 (ring stage) +
         // j*8192 (tap) + nt*2048
@@ -297,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, qb, cb);
+                if (u + 2 < nunits) issue_w(u + 2, qb, cb);
                 SD_CONV_RD(1, 0, xP, wP);
                 mma16(xQ, wQ, 0, dm0 & hm1);
             }
@@ -316,8 +313,8 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, qb, cb);
-                if (T + 2 < ntiles && !(a.dbg & 2)) issue_a(T + 2, qc, cc);
+                if (u + 2 < nunits) issue_w(u + 2, qb, cb);
+                if (T + 2 < ntiles) issue_a(T + 2, qc, cc);
                 const int lastmask = dm1 & hm1;
                 if (T + 1 < ntiles) {
                     setup(T + 1, qb);
@@ -339,7 +336,6 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
         const bool ok0 = (unsigned)jw0 < 4u, ok1 = (unsigned)jw1 < 4u;
         int dmA[2] = {tile_mask(td_, pd), tile_mask(td_, pd - 1)};                          // [ad]
         const int hmA[2] = {tile_mask(th_, ph), tile_mask(th_, ph - 1)};                    // [ah]
-        if (a.dbg & 4) dmA[0] = dmA[1] = 0;
         unsigned xb[2][2][4];                        // [aw][k-step][tile] of the CURRENT tile; immediate (1 - ad)*2048 + (1 - ah)*512 on top
         auto setup = [&](int T) {
             const unsigned abuf = lds0 + SD_A0 + (T & 1) * SD_ATILE;
@@ -387,9 +383,9 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (u + 2 < nunits && !(a.dbg & 1)) issue_w(u + 2, 0, 0);
+                if (u + 2 < nunits) issue_w(u + 2, 0, 0);
                 if (A == 7) {
-                    if (T + 2 < ntiles && !(a.dbg & 2)) issue_a(T + 2, 0, 0);
+                    if (T + 2 < ntiles) issue_a(T + 2, 0, 0);
                     if (T + 1 < ntiles) {
                         setup(T + 1);
                         SD_T_X(AN, 0, xP); SD_T_W(AN, wbt0, 0, wP);
@@ -558,7 +554,6 @@ int sd_launch(const void *x, const void *w, const float *scale, const float *shi
         a.x_bytes = (unsigned)((size_t)nb * sample_in);
         a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
         a.groups = MODE == 0 ? cout / 64 : 4 * (cout / 128);
-        { const char *e = getenv("VV_SD_DBG"); a.dbg = e ? atoi(e) : 0; }
         const int nsg = (nb + 3) / 4;
         VV_LAUNCH(sd_kernel<MODE>, dim3(nsg * a.groups), dim3(512), SD_LDS, st, a);
         const int rc = vv_launch_status();
