@@ -656,6 +656,46 @@ def _check_fp8_out(got_f8, ref, what):
     assert not bad.any(), '%s: %d of %d beyond fp8 rounding, worst %.3e' % (what, bad.sum(), bad.size, np.abs(got - ref).max())
 
 
+def test_widest_layers_full_batch_forms_agree(L, monkeypatch):
+    """B = 256: the whole-sample D4 kernel in both MFMA shapes and both parity splits equals the halo-tile kernel bit for bit, and
+    the two MFMA shapes of the E2 kernel equal each other (same bf16 operands, same float32 accumulation order per output up to
+    the MFMA's internal tree -- measured identical)."""
+    B = 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    sc = torch.rand(128, device=DEV, generator=g) + 0.5
+    sh = torch.randn(128, device=DEV, generator=g) * 0.3
+    # D4: 8^3 x 128 -> 16^3 x 64
+    x = torch.randn(B, 8, 8, 8, 128, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(4, 4, 4, 64, 128, device=DEV, generator=g) / 32).contiguous()
+    wf = torch.empty(64 * 128 * 64, dtype=torch.bfloat16, device=DEV)
+    wk = torch.empty_like(wf)
+    L.call('vv_pack_convT_k4s2_frag', L.ptr(w), L.ptr(wf), 128, 64, _st())
+    L.call('vv_pack_convT_k4s2_skip', L.ptr(w), L.ptr(wk), 128, 64, _st())
+    y0 = torch.full((B, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wf), L.ptr(sc), L.ptr(sh), L.ptr(y0), B, 8, 128, 64, 1, L.VV_BF16, _st())
+    for shape in ('16', '32'):
+        for ps in ('1', '2'):
+            monkeypatch.setenv('VV_CTW_SHAPE', shape)
+            monkeypatch.setenv('VV_CTW_PS', ps)
+            y1 = torch.full_like(y0, float('nan'))
+            L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(x), L.ptr(wk), L.ptr(sc), L.ptr(sh), L.ptr(y1), B, 8, 128, 64, 1, L.VV_BF16, _st())
+            torch.cuda.synchronize()
+            assert torch.equal(y0, y1), 'whole-sample D4, MFMA shape %s, %s parity split(s)' % (shape, ps)
+    # E2: 16^3 x 64 -> 8^3 x 128
+    x2 = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(4, 4, 4, 64, 128, device=DEV, generator=g) / 64).contiguous()
+    wp = torch.empty(128, 64 * 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(w2), L.ptr(wp), 64, 128, L.VV_BF16, _st())
+    outs = []
+    for shape in ('16', '32'):
+        monkeypatch.setenv('VV_CD_SHAPE', shape)
+        y = torch.full((B, 8, 8, 8, 128), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x2), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 16, 64, 128, 1, L.VV_BF16, _st())
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
+
+
 def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
     """B = 256 (BASELINE configs[1]: several items / steps per persistent workgroup, two workgroups per CU): the plane form of the
     first layer equals its gather form bit for bit, and the depth-sweep form of the last layer equals the 4^3-box form (logits to
