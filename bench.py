@@ -400,7 +400,8 @@ def main():
 
         dth = time_steps(host_call, 10, 3)
         h2d = {'value': a.batch / dth, 'unit': 'reconstructions/s', 'ms_per_call': 1e3 * dth,
-               'what': 'getEval(numpy x, y, one-hot) -> np.array(pred): 2 x %.1f MB host->device + %.1f MB device->host per call, pageable host memory'
+               'what': 'getEval(numpy x, x, one-hot) -> np.array(pred): %.1f MB host->device (input and target are the same array, as in '
+                       'test_modelnet_VAE.py:115: uploaded once) + %.1f MB device->host per call, pageable host memory'
                        % (xh.nbytes / 1e6, xh.nbytes / 1e6)}
         # BASELINE.json configs[0]: the AE at batch 4 (test_modelnet_AE.py plumbing), CPU oracle and GPU on the same inputs
         cfg_ae = syn.make_config(a.voxel, a.latent, False)
