@@ -516,8 +516,9 @@ def test_surveyed_edge_cases():
     np.testing.assert_allclose(z[2], 0.25, atol=1e-7)
 
 
-def test_streamed_evaluator_matches_one_batch_at_a_time():
-    """voxvae.streams.StreamedEvaluator: independent batches issued round-robin on 3 HIP streams (one engine replica each) give
+@pytest.mark.parametrize('B,nb,ns', [(48, 7, 3), (256, 6, 2)])      # 256 x 2 streams = bench.py's default: kernels of two steps share CUs
+def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns):
+    """voxvae.streams.StreamedEvaluator: independent batches issued round-robin on 2 or 3 HIP streams (one engine replica each) give
     bit-identical per-sample sums, metrics and KL to the same batches run one at a time on one stream -- the replicas share
     nothing but the (read-only) inputs."""
     import contextlib
@@ -539,12 +540,12 @@ def test_streamed_evaluator_matches_one_batch_at_a_time():
         m._decoder.set_weights_dict(dp)
         return m
 
-    batches = [(torch.from_numpy(syn.make_voxels(48, 32, seed=50 + i)).to(DEV), torch.from_numpy(syn.make_eps(48, 64, seed=60 + i)).to(DEV))
-               for i in range(7)]
+    batches = [(torch.from_numpy(syn.make_voxels(B, 32, seed=50 + i)).to(DEV), torch.from_numpy(syn.make_eps(B, 64, seed=60 + i)).to(DEV))
+               for i in range(nb)]
     ref_model = build()
     ref = [ref_model.eval_forward_device(x, x, e) for x, e in batches]
     torch.cuda.synchronize()
-    ev = StreamedEvaluator(build, streams=3, device=DEV)
+    ev = StreamedEvaluator(build, streams=ns, device=DEV)
     got = [ev.submit(x, x, e) for x, e in batches]
     ev.synchronize()
     for (p0, s0, m0, k0), (p1, s1, m1, k1) in zip(ref, got):
