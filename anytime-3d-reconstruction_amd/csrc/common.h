@@ -46,6 +46,18 @@ static inline int vv_log2(int v) {
     while ((1 << l) < v) ++l;
     return l;
 }
+// Buffer descriptors carry 32-bit offsets: a launch covers at most 2 GiB of its largest per-sample-indexed tensor; larger batches
+// go out as several launches over sample ranges (samples are independent).  VV_CHUNK_SAMPLES caps the range (tests).
+#include <stdlib.h>
+static inline int vv_chunk_samples(size_t sample_bytes, int batch) {
+    size_t per = sample_bytes ? 0x7FFFFFFFull / sample_bytes : (size_t)batch;
+    if (const char *e = getenv("VV_CHUNK_SAMPLES")) {
+        const long v = atol(e);
+        if (v > 0 && (size_t)v < per) per = (size_t)v;
+    }
+    if (per > (size_t)batch) per = (size_t)batch;
+    return (int)per;
+}
 static inline bool vv_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t vv_dtype_size(int dt) { return dt == VV_BF16 ? 2 : (dt == VV_FP8 ? 1 : 4); }
 // hipGetLastError() is per-thread and may hold a stale error from the host framework: clear it, then launch.

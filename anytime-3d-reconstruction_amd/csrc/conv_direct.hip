@@ -458,8 +458,6 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
     if (out_dtype != VV_BF16 && out_dtype != VV_FP8) return VV_ERR_DTYPE;
     if (!vv_conv3d_k4s2_direct_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w_packed) || !vv_aligned16(y)) return VV_ERR_ALIGN;
-    const size_t xb = (size_t)batch * side * side * side * cin * 2;
-    if (xb >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
     const int so = side / 2;
     const int boxes = (so / 4) * (so / 8) * (so / 8);
     static const bool attr = [] {
@@ -469,15 +467,26 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
     }();
     (void)attr;
     const char *se = getenv("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
-    if (!se || atoi(se) != 32)
-        VV_LAUNCH(conv_direct16_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
-                  reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
-                  vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
-    else
-        VV_LAUNCH(conv_direct_kernel, dim3(batch * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream),
-                  reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_packed), scale, shift, y,
-                  vv_log2(so), (unsigned)xb, (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
-    return vv_launch_status();
+    const bool s16 = !se || atoi(se) != 32;
+    const size_t in_per = (size_t)side * side * side * cin * 2, out_per = (size_t)so * so * so * cout * (out_dtype == VV_FP8 ? 1 : 2);
+    const int per = vv_chunk_samples(in_per, batch);
+    if (per < 1) return VV_ERR_SHAPE;
+    for (int b0 = 0; b0 < batch; b0 += per) {
+        const int nb = batch - b0 < per ? batch - b0 : per;
+        const __bf16 *xc = reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per);
+        void *yc = reinterpret_cast<char *>(y) + (size_t)b0 * out_per;
+        if (s16)
+            VV_LAUNCH(conv_direct16_kernel, dim3(nb * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream), xc,
+                      reinterpret_cast<const __bf16 *>(w_packed), scale, shift, yc, vv_log2(so), (unsigned)((size_t)nb * in_per),
+                      (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
+        else
+            VV_LAUNCH(conv_direct_kernel, dim3(nb * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream), xc,
+                      reinterpret_cast<const __bf16 *>(w_packed), scale, shift, yc, vv_log2(so), (unsigned)((size_t)nb * in_per),
+                      (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);
+        const int rc = vv_launch_status();
+        if (rc != VV_OK) return rc;
+    }
+    return VV_OK;
 }
 
 VV_EXPORT int vv_conv3d_k4s2_direct_fwd(const void *x, const void *w_packed, const float *scale, const float *shift, void *y,

@@ -287,8 +287,6 @@ VV_EXPORT int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, cons
     if (!x || !w_frag || !y) return VV_ERR_NULL;
     if (!vv_convT3d_k4s2_direct_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w_frag) || !vv_aligned16(y)) return VV_ERR_ALIGN;
-    const size_t xb = (size_t)batch * side * side * side * cin * 2;
-    if (xb >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
     // variants: "2" = 2x4x8 cells, 4 waves x 2 parities, 2 workgroups / CU; "4" = 4x4x8 cells, 4 waves x 2 parities;
     // "8" = 4x4x8 cells, 8 waves x 1 parity (each weight fragment feeds 4 MFMAs, 2 waves / SIMD)
     const char *sel_env = getenv("VV_DIRECT_MT");                       // read per call so that tests can cover every variant
@@ -304,8 +302,16 @@ VV_EXPORT int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, cons
             return true;
         }();
         (void)attr;
-        VV_LAUNCH((convT_direct_kernel<128, 64, MT, NW>), dim3(batch * boxes), dim3(NW * 64), LDS, st, reinterpret_cast<const __bf16 *>(x),
-                  reinterpret_cast<const __bf16 *>(w_frag), scale, shift, reinterpret_cast<__bf16 *>(y), vv_log2(side), (unsigned)xb, act);
+        const size_t in_per = (size_t)side * side * side * cin * 2, out_per = (size_t)8 * side * side * side * cout * 2;
+        const int per = vv_chunk_samples(in_per, batch);           // 32-bit buffer offsets: <= 2 GiB of input per launch
+        for (int b0 = 0; b0 < batch && per > 0; b0 += per) {
+            const int nb = batch - b0 < per ? batch - b0 : per;
+            VV_LAUNCH((convT_direct_kernel<128, 64, MT, NW>), dim3(nb * boxes), dim3(NW * 64), LDS, st,
+                      reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per),
+                      reinterpret_cast<const __bf16 *>(w_frag), scale, shift,
+                      reinterpret_cast<__bf16 *>(reinterpret_cast<char *>(y) + (size_t)b0 * out_per), vv_log2(side),
+                      (unsigned)((size_t)nb * in_per), act);
+        }
     };
     if (sel == 8) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 8>{});
     else if (sel == 4) launch(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});

@@ -841,8 +841,17 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
             return true;
         }();
         (void)attr;
-        VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * batch), dim3(256), SW_LDS, st, reinterpret_cast<const __bf16 *>(x), w_keras, target,
-                  probs, logits, partials, vv_log2(side), (unsigned)((size_t)batch * side * side * side * FB_CIN * 2), gamma, epsilon);
+        // 32-bit buffer offsets: <= 2 GiB of input per launch; every per-sample tensor moves on by the same sample range
+        const size_t in_per = (size_t)side * side * side * FB_CIN * 2, vox = (size_t)8 * side * side * side;
+        const int per = vv_chunk_samples(in_per, batch);
+        if (per < 1) return VV_ERR_SHAPE;
+        for (int b0 = 0; b0 < batch; b0 += per) {
+            const int nbt = batch - b0 < per ? batch - b0 : per;
+            VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * nbt), dim3(256), SW_LDS, st,
+                      reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per), w_keras, target + (size_t)b0 * vox,
+                      probs ? probs + (size_t)b0 * vox : nullptr, logits ? logits + (size_t)b0 * vox : nullptr, partials + (size_t)b0 * ntile * 4,
+                      vv_log2(side), (unsigned)((size_t)nbt * in_per), gamma, epsilon);
+        }
         finish_stats(partials, stats, metrics4, ntile, batch, st);
         return vv_launch_status();
     }

@@ -656,6 +656,67 @@ def _check_fp8_out(got_f8, ref, what):
     assert not bad.any(), '%s: %d of %d beyond fp8 rounding, worst %.3e' % (what, bad.sum(), bad.size, np.abs(got - ref).max())
 
 
+def test_launch_chunking_over_sample_ranges(L, monkeypatch):
+    """Tensors past 2 GiB go out as several launches over sample ranges (32-bit buffer offsets).  VV_CHUNK_SAMPLES forces the
+    same code path at a small batch: results are bit-identical to the single launch for the E2 kernel, the halo-tile D4 kernel
+    and the sweep-form last layer (logits, probabilities and the four loss sums)."""
+    B = 11
+    g = torch.Generator(device=DEV).manual_seed(3)
+    sc = torch.rand(128, device=DEV, generator=g) + 0.5
+    sh = torch.randn(128, device=DEV, generator=g) * 0.3
+
+    def both(fn):
+        monkeypatch.delenv('VV_CHUNK_SAMPLES', raising=False)
+        a = fn()
+        monkeypatch.setenv('VV_CHUNK_SAMPLES', '4')
+        b = fn()
+        monkeypatch.delenv('VV_CHUNK_SAMPLES')
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+    x2 = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=g).to(torch.bfloat16)
+    w2 = (torch.randn(4, 4, 4, 64, 128, device=DEV, generator=g) / 64).contiguous()
+    wp = torch.empty(128, 64 * 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(w2), L.ptr(wp), 64, 128, L.VV_BF16, _st())
+
+    def e2():
+        y = torch.full((B, 8, 8, 8, 128), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x2), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 16, 64, 128, 1, L.VV_BF16, _st())
+        torch.cuda.synchronize()
+        return (y,)
+    both(e2)
+
+    x4 = torch.randn(B, 8, 8, 8, 128, device=DEV, generator=g).to(torch.bfloat16)
+    w4 = (torch.randn(4, 4, 4, 64, 128, device=DEV, generator=g) / 32).contiguous()
+    wf = torch.empty(64 * 128 * 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_frag', L.ptr(w4), L.ptr(wf), 128, 64, _st())
+
+    def d4():
+        y = torch.full((B, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(x4), L.ptr(wf), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 8, 128, 64, 1, L.VV_BF16, _st())
+        torch.cuda.synchronize()
+        return (y,)
+    both(d4)
+
+    Bs = 37                                            # sweep form needs batch * tiles >= 128
+    xa = torch.randn(Bs, 16, 16, 16, 64, device=DEV, generator=g).to(torch.bfloat16)
+    w5 = (torch.randn(4, 4, 4, 1, 64, device=DEV, generator=g) / 16).contiguous()
+    tgt = (torch.rand(Bs, 32, 32, 32, 1, device=DEV, generator=g) < 0.1).float().contiguous()
+    ws = torch.empty(max(L.load().vv_convT3d_final_bce_workspace_bytes(Bs, 16), 16), dtype=torch.uint8, device=DEV)
+    monkeypatch.setenv('VV_FINAL_BCE', 'sweep')
+
+    def d5():
+        lg = torch.full((Bs, 32, 32, 32, 1), float('nan'), device=DEV)
+        pr = torch.full_like(lg, float('nan'))
+        st = torch.empty(Bs, 4, device=DEV)
+        L.call('vv_convT3d_final_bce_fwd', L.ptr(xa), L.ptr(w5), L.ptr(tgt), L.ptr(pr), L.ptr(lg), L.ptr(st), Bs, 16, 64, 0.6, 1e-7, L.VV_BF16,
+               L.ptr(ws), ws.numel(), _st())
+        torch.cuda.synchronize()
+        return lg, pr, st
+    both(d5)
+
+
 def test_widest_layers_full_batch_forms_agree(L, monkeypatch):
     """B = 256: the whole-sample D4 kernel in both MFMA shapes and both parity splits equals the halo-tile kernel bit for bit, and
     the two MFMA shapes of the E2 kernel equal each other (same bf16 operands, same float32 accumulation order per output up to
