@@ -550,3 +550,37 @@ def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns):
     ev.synchronize()
     for (p0, s0, m0, k0), (p1, s1, m1, k1) in zip(ref, got):
         assert torch.equal(s0, s1) and torch.equal(m0, m1) and torch.equal(k0, k1) and torch.equal(p0, p1)
+
+
+def test_eval_step_as_hip_graph_is_identical():
+    """voxvae.graphs.GraphedEvalStep: the 13 launches of an evaluation step are capturable (every launch goes to the capturing
+    stream, every buffer comes from torch's allocator) and a replay reproduces the eager outputs bit for bit, also after the
+    inputs were replaced."""
+    import contextlib
+    import sys
+    import voxvae
+    from voxvae import synthetic as syn
+    from voxvae.graphs import GraphedEvalStep
+    voxvae.set_default_dtype('bf16')
+    DEV = 'cuda:0'
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(32, 64, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+
+    def build():
+        with contextlib.redirect_stdout(sys.stderr):
+            m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+        m._encoder.set_weights_dict(ep)
+        m._decoder.set_weights_dict(dp)
+        return m
+    B = 6
+    xs = [torch.from_numpy(syn.make_voxels(B, 32, seed=70 + i)).to(DEV) for i in range(2)]
+    es = [torch.from_numpy(syn.make_eps(B, 64, seed=80 + i)).to(DEV) for i in range(2)]
+    eager, graphed = build(), build()
+    g = GraphedEvalStep(graphed, xs[0], xs[0], es[0])
+    for x, e in zip(xs, es):
+        ref = eager.eval_forward_device(x, x, e)
+        out = g(x, None, e)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))
