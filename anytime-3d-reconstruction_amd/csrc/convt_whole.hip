@@ -244,7 +244,8 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
 }
 
 
-// ---- the same kernel on v_mfma_f32_16x16x32_bf16: same LDS images, same chunk / ring / barrier scheme; a wave's 64 x 64 tile
+// ---- the same kernel on v_mfma_f32_16x16x32_bf16: same chunk / ring / barrier scheme, x tile slot key (2 zw) & 15 (conflict-free
+// for every tap shift in this fragment shape, scratch/ctw_swz.py; the key v & 15 of the 32x32x16 form is 2-way on odd w shifts); a wave's 64 x 64 tile
 // is 4 x 4 accumulators of 16 x 16 (16 cells = two h-rows, 16 channels), 8 fragment reads and 16 MFMAs per 32-deep k-step.
 // On random data the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
 #define CW16_LD(F, XA, WA)                                                                                                          \
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
         for (int i = 0; i < 16; ++i) {
             const int it = i * 8 + wave;
             const int v = it * 4 + vsub;
-            vv_dma16(rsx, (unsigned)(v * 256 + ((pos ^ (v & 15)) << 4)), lds0 + it * 1024);
+            vv_dma16(rsx, (unsigned)(v * 256 + ((pos ^ ((2 * v) & 15)) << 4)), lds0 + it * 1024);    // slot key (2 zw) & 15, zw = v & 7
         }
     }
     const unsigned wv = (unsigned)((wave * 8 + (lane >> 3)) * 128 + (((lane & 7) ^ (((wave * 8 + (lane >> 3)) >> 1) & 7)) << 4));
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
         const int dd = pd - ((A >> 2) & 1), dh = ph - ((A >> 1) & 1), dw = pw - (A & 1);
         const bool okw = (unsigned)(wave + dd) < 8u && (unsigned)(rw + dw) < 8u;
         const int sft = dd * 64 + dh * 8 + dw;
-        const unsigned key = ((unsigned)((r + dh * 8 + dw) ^ q) & 15u) << 4;
+        const unsigned key = ((unsigned)((2 * (rw + dw)) ^ q) & 15u) << 4;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const unsigned row = okw && (unsigned)(2 * ct + rh + dh) < 8u ? R0 + (unsigned)((sft + 16 * ct) << 8) : ZR;
