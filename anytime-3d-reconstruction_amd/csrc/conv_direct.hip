@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__r
     // ---- consumer addressing (LDS byte addresses).  lane = (r, kq): row r of a 16-row fragment, k quarter kq of a 32-deep
     // k-step; a wave's 64 outputs are 4 cell tiles of two output h-rows (rows 2 ct, 2 ct + 1: +18 tile rows = +2304 B each),
     // its 64 channels 4 tiles of 16 weight rows (+2048 B each).  Slot key of a tile row: (2 jw) & 7 -- conflict-free for
-    // every tap and every ds_read_b128 lane group in this fragment shape (scratch search over all keys a jw + b jh + c zd).
+    // every tap and every ds_read_b128 lane group in this fragment shape (profiles/microbench/e2_swz.py: search over all keys a jw + b jh + c zd).
     const int r = lane & 15, kq = lane >> 4;
     const int rl0 = wm * 81 + (r >> 3) * 9 + (r & 7);
     unsigned xo[2][2], wo[2];                      // [aw][k-step] inside tile 0 / [k-step] inside weight stage 0

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
 
 
 // ---- the same kernel on v_mfma_f32_16x16x32_bf16: same chunk / ring / barrier scheme, x tile slot key (2 zw) & 15 (conflict-free
-// for every tap shift in this fragment shape, scratch/ctw_swz.py; the key v & 15 of the 32x32x16 form is 2-way on odd w shifts); a wave's 64 x 64 tile
+// for every tap shift in this fragment shape, profiles/microbench/ctw_swz.py; the key v & 15 of the 32x32x16 form is 2-way on odd w shifts); a wave's 64 x 64 tile
 // is 4 x 4 accumulators of 16 x 16 (16 cells = two h-rows, 16 channels), 8 fragment reads and 16 MFMAs per 32-deep k-step.
 // On random data the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7).
 #define CW16_LD(F, XA, WA)                                                                                                          \

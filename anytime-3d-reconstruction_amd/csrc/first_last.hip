@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     auto stage = [&](int d, int sp) {              // sp = d % SW_NX, passed so that the unrolled steps see a constant
         // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
         // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
-        // B = 256 cross-check against the box form, scratch/chk_e1_d5.py.)
+        // B = 256 cross-check against the box form, profiles/microbench/chk_e1_d5.py.)
         const bool din = (unsigned)d < (unsigned)n;
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
         const unsigned slot = ldsx + sp * SW_XB;

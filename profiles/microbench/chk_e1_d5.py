@@ -1,0 +1,77 @@
+"""B = 256 cross-checks: plane-form first layer vs gather form; sweep-form last layer vs box form; repeated for determinism."""
+import ctypes, os, sys
+import torch
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'anytime-3d-reconstruction_amd'))
+from voxvae import lib as L
+lib = L.load()
+DEV = 'cuda:0'
+B = 256
+cs = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+torch.manual_seed(1)
+x = (torch.rand(B, 32, 32, 32, 1, device=DEV) < 0.1).float().contiguous()
+w = (torch.randn(4, 4, 4, 1, 64, device=DEV) / 8).float().contiguous()
+sc = torch.rand(64, device=DEV) + 0.5; sh = torch.randn(64, device=DEV) * 0.3
+wp = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+L.call('vv_pack_conv_k4', L.ptr(w), L.ptr(wp), 1, 64, L.VV_BF16, cs)
+def e1():
+    y = torch.full((B, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 32, 64, 1, L.VV_BF16, cs)
+    torch.cuda.synchronize()
+    return y
+ys = [e1() for _ in range(4)]
+os.environ['VV_FIRSTCONV_GATHER'] = '1'
+yg = e1()
+os.environ.pop('VV_FIRSTCONV_GATHER')
+for i, y in enumerate(ys):
+    d = (y.float() - yg.float()).abs()
+    print('E1 run', i, 'max diff vs gather', d.max().item(), 'n>0.05', (d > 0.05).sum().item(), 'nan', torch.isnan(y.float()).sum().item(), 'equal run0', torch.equal(y, ys[0]))
+
+xa = torch.randn(B, 16, 16, 16, 64, device=DEV).to(torch.bfloat16)
+w5 = (torch.randn(4, 4, 4, 1, 64, device=DEV) / 16).float().contiguous()
+tgt = (torch.rand(B, 32, 32, 32, 1, device=DEV) < 0.1).float().contiguous()
+ws = torch.empty(max(lib.vv_convT3d_final_bce_workspace_bytes(B, 16), 16), dtype=torch.uint8, device=DEV)
+def d5():
+    lg = torch.full((B, 32, 32, 32, 1), float('nan'), device=DEV); pr = torch.empty_like(lg)
+    st = torch.empty(B, 4, device=DEV)
+    L.call('vv_convT3d_final_bce_fwd', L.ptr(xa), L.ptr(w5), L.ptr(tgt), L.ptr(pr), L.ptr(lg), L.ptr(st), B, 16, 64, 0.6, 1e-7, L.VV_BF16, L.ptr(ws), ws.numel(), cs)
+    torch.cuda.synchronize()
+    return lg, st
+rs = [d5() for _ in range(4)]
+os.environ['VV_FINAL_BCE'] = 'box'
+lb, sb = d5()
+os.environ.pop('VV_FINAL_BCE')
+for i, (lg, st) in enumerate(rs):
+    d = (lg - lb).abs()
+    print('D5 run', i, 'max logit diff vs box', d.max().item(), 'n>1e-3', (d > 1e-3).sum().item(), 'stats diff', (st - sb).abs().max().item(), 'equal run0', torch.equal(lg, rs[0][0]))
+lg = rs[0][0].view(B, 32, 32, 32)
+bad = ((lg - lb.view(B, 32, 32, 32)).abs() > 1e-3).nonzero()
+print('bad count', bad.shape[0])
+import collections
+for ax, name in ((0, 'b'), (1, 'od'), (2, 'oh'), (3, 'ow')):
+    c = collections.Counter(bad[:, ax].tolist())
+    print(name, sorted(c.items())[:40])
+# per (b, tile) counts
+c = collections.Counter(((r[0].item()), r[2].item() // 16, r[3].item() // 16) for r in bad)
+print('tiles', len(c), sorted(c.items())[:20])
+# loss sums from the logits in float64
+l64 = lb.double().view(B, -1); t64 = tgt.double().view(B, -1)
+p = torch.sigmoid(l64); q = p.clamp(1e-7, 1 - 1e-7)
+bce = -(0.6 * t64 * q.log() + 0.4 * (1 - t64) * (1 - q).log()).sum(1)
+yh = (l64 >= 0).double()
+ref = torch.stack([bce, (t64 * yh).sum(1), ((1 - t64) * yh).sum(1), (t64 * (1 - yh)).sum(1)], 1)
+print('box   vs f64:', (sb.double() - ref).abs().max(0).values.tolist())
+for i, (lg, st) in enumerate(rs):
+    print('sweep', i, 'vs f64:', (st.double() - ref).abs().max(0).values.tolist())
+for i, (lg, st) in enumerate(rs):
+    l2 = lg.double().view(B, -1)
+    yh2 = (l2 >= 0).double()
+    fp2 = ((1 - t64) * yh2).sum(1)
+    print('sweep', i, 'sign mismatches vs box', ((l2 >= 0) != (l64 >= 0)).sum().item(), 'FP(stats) - FP(own logits) max', (st[:, 2].double() - fp2).abs().max().item(),
+          'samples off', ((st[:, 2].double() - fp2).abs() > 0).sum().item(), 'nan logits', torch.isnan(l2).sum().item())
+lg, st = rs[0]
+l2 = lg.double().view(B, -1); yh2 = (l2 >= 0).double()
+fp2 = ((1 - t64) * yh2).sum(1)
+dd = (st[:, 2].double() - fp2)
+idx = dd.abs().nonzero().flatten()[:12]
+print('signed FP diffs', [(int(i), dd[i].item()) for i in idx])
+print('bce diff at those', [(st[i, 0].double() - ref[i, 0]).item() for i in idx])

@@ -1,0 +1,28 @@
+"""Host time to submit one evaluation step (13 launches through ctypes + torch allocations) against the GPU's step time."""
+import contextlib, json, sys, time
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'anytime-3d-reconstruction_amd'))
+import numpy as np, torch
+import voxvae
+from voxvae import synthetic as syn
+voxvae.set_default_dtype('bf16'); voxvae.set_default_device('cuda:0')
+import src.module.nolbo as nolbo
+cfg = syn.make_config(32, 64, True)
+ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+def build():
+    with contextlib.redirect_stdout(sys.stderr):
+        m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(ep); m._decoder.set_weights_dict(dp)
+    return m
+for B in (256, 8):
+    x = torch.from_numpy(syn.make_voxels(B, 32, seed=1234)).cuda(); eps = torch.from_numpy(syn.make_eps(B, 64, seed=7)).cuda()
+    for NS in (1, 2):
+        models = [build() for _ in range(NS)]
+        streams = [torch.cuda.Stream() for _ in range(NS)]
+        def run(steps):
+            for i in range(steps):
+                with torch.cuda.stream(streams[i % NS]):
+                    models[i % NS].eval_forward_device(x, x, eps)
+        torch.cuda.synchronize()
+        run(50); torch.cuda.synchronize()
+        t0 = time.perf_counter(); run(400); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        print(json.dumps({'batch': B, 'streams': NS, 'submit_ms_per_step': round(1e3 * (t1 - t0) / 400, 4), 'total_ms_per_step': round(1e3 * (t2 - t0) / 400, 4)}), flush=True)
