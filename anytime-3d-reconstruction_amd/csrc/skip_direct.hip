@@ -326,7 +326,13 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
             qc = cb + 1 < NC ? qb : qb + 1; cc = cb + 1 < NC ? cb + 1 : 0;
             (void)qa; (void)ca;
         }
+        // Nothing of the epilogue may be scheduled above this wait: to the compiler an asm output is a ready value, and it placed
+        // the epilogue's first address / select instructions -- into registers of the look-ahead fragments -- in front of it
+        // (tests/isa_lint.py walks the generated code for exactly that; the `T + 1 < ntiles` guard makes that path infeasible
+        // here, which neither the scheduler nor the lint can know).  Naming the fragments as "+v" here instead made them live
+        // out of the loop and the compiler COPIED in-flight registers at the loop head (also caught by the lint).
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #undef SD_CONV_RD
     } else {
         // tap (ad, ah, aw) of parity (pd, ph, hv) reads cell (d + pd - ad, h + ph - ah, w + hv - aw)
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
             unit(std::integral_constant<int, 7>{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);              // as in the conv form: the epilogue stays below the wait
 #undef SD_T_X
 #undef SD_T_W
     }

@@ -186,7 +186,14 @@ class _ModelnetBase(object):
         tr = self._train_helper()
         if len(inputs) == 2 or category_vectors is None:
             x, y = self._dev_pair(inputs[0], inputs[1])
-            _, _, probs, _, m = tr.forward_training_mode(x, y, None if _eps is None else self._dev(_eps))
+            zero = None
+            if missing_prob > 0:     # legacy body nolbo.py:1544-1548: masked entries become 0 (as in _getEval_legacy)
+                Bz, Lz = x.shape[0], self._latent_dim
+                if _mask is None:
+                    _mask = np.reshape(np.random.choice(2, Bz * Lz, p=[missing_prob, 1. - missing_prob]), [Bz, Lz]).astype('float32')
+                mk = self._dev(_mask)
+                zero = lambda z: self._zero_masked(z, mk)[0]
+            _, _, probs, _, m = tr.forward_training_mode(x, y, None if _eps is None else self._dev(_eps), z_fn=zero)
             return DeviceArray(probs), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
         input_images, output_images, category_list = inputs
         x, y = self._dev_pair(input_images, output_images)
@@ -222,6 +229,19 @@ class _ModelnetBase(object):
         self._z_category_corrected = DeviceArray(zc)
         return res + (DeviceArray(probs_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
 
+    def _zero_masked(self, z, mask):
+        """where(mask == 0, 0, z) (legacy body nolbo.py:1544-1548): the latent_correct kernel with a zero prototype table and
+        zero epsilon.  Returns (float32, activation-dtype) copies."""
+        B, Lz = z.shape
+        zeros = torch.zeros(1, Lz, dtype=torch.float32, device=self._device)
+        idx0 = torch.zeros(B, dtype=torch.int32, device=self._device)
+        e0 = torch.zeros(B, Lz, dtype=torch.float32, device=self._device)
+        zc = torch.empty_like(z)
+        zc_act = zc if self._act_dt == _L.VV_F32 else torch.empty(B, Lz, dtype=torch.bfloat16, device=self._device)
+        _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(zeros), _L.ptr(idx0), _L.ptr(e0), _L.ptr(zc),
+                None if zc_act is zc else _L.ptr(zc_act), self._act_dt, B, Lz, _st())
+        return zc, zc_act
+
     def _getEval_legacy(self, inputs, missing_prob, _eps, _mask):
         input_images, output_images = inputs[0], inputs[1]
         x, y = self._dev_pair(input_images, output_images)
@@ -230,16 +250,7 @@ class _ModelnetBase(object):
             B, Lz = z.shape
             if _mask is None:
                 _mask = np.reshape(np.random.choice(2, B * Lz, p=[missing_prob, 1. - missing_prob]), [B, Lz]).astype('float32')
-            mask = self._dev(_mask)
-            # where(mask == 0, 0, z): the latent_correct kernel with a zero prototype table and zero epsilon
-            zeros = torch.zeros(1, Lz, dtype=torch.float32, device=self._device)
-            idx0 = torch.zeros(B, dtype=torch.int32, device=self._device)
-            e0 = torch.zeros(B, Lz, dtype=torch.float32, device=self._device)
-            zc = torch.empty_like(z)
-            zc_act = zc if self._act_dt == _L.VV_F32 else torch.empty(B, Lz, dtype=torch.bfloat16, device=self._device)
-            _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(zeros), _L.ptr(idx0), _L.ptr(e0), _L.ptr(zc),
-                    None if zc_act is zc else _L.ptr(zc_act), self._act_dt, B, Lz, _st())
-            z_act = zc_act
+            _, z_act = self._zero_masked(z, self._dev(_mask))
         pred, _, m = self._decode_metrics(z_act, y)
         return DeviceArray(pred), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2])
 
@@ -530,11 +541,10 @@ class nolboSingleObject_modelnet_category_only(_ModelnetBase):
 
     def getEval(self, inputs, category_indices=np.identity(40), training=False, missing_prob=0.0, *, _eps=None, _mask=None, _eps2=None):
         """nolbo.py:1678-1754 -> the 10-tuple of the VAE class, classified / corrected against the prior means."""
-        if training:
-            raise NotImplementedError('getEval(training=True) is not used by any reference caller')
-        mean_prior, _ = self._priornet_class(np.asarray(category_indices, dtype='float32'), training=False)
-        return _ModelnetBase.getEval(self, inputs, category_vectors=mean_prior.detach().contiguous(), missing_prob=missing_prob,
-                                     _eps=_eps, _mask=_mask, _eps2=_eps2)
+        # reference :1686, :1691, :1724: `training` goes to the prior network, the encoder and the decoder alike
+        mean_prior, _ = self._priornet_class(np.asarray(category_indices, dtype='float32'), training=bool(training))
+        return _ModelnetBase.getEval(self, inputs, category_vectors=mean_prior.detach().contiguous(), training=training,
+                                     missing_prob=missing_prob, _eps=_eps, _mask=_mask, _eps2=_eps2)
 
     def savePriorCategory(self, save_path):
         self._priornet_class.save_weights(os.path.join(save_path, self._prior_class_str['name']))

@@ -193,10 +193,24 @@ class Model(object):
         self._engine.set_params(params)
 
     def __call__(self, inputs, training=False):
-        if training:
-            raise NotImplementedError('training=True (batch-statistics BatchNorm) is driven by the model classes\' fit()')
+        """model(x, training) of the reference's callers (nolbo.py:1426 `self._decoder(z, training=True)`, AE3D.py:72-73).
+        training=True: BatchNorm normalises with the statistics of this batch and moves its moving statistics (momentum
+        0.99), exactly what the Keras layers do under training=True; nothing else changes (no optimiser step)."""
         dev = self._engine.device
         x = as_device_f32(inputs, dev)
+        if training:
+            from voxvae import train as _train
+            if getattr(self, '_fwd_train', None) is None:
+                self._fwd_train = (_train.Trainer.forward_only(enc=self._engine) if self._kind == 'encoder'
+                                   else _train.Trainer.forward_only(dec=self._engine))
+            if self._kind == 'encoder':
+                return DeviceArray(self._fwd_train.encoder_training_mode(x))
+            eng = self._engine
+            y0 = torch.zeros(x.shape[0], eng.D, eng.D, eng.D, 1, dtype=torch.float32, device=dev)
+            if not eng.final_sigmoid:
+                raise NotImplementedError("decoder(z, training=True) with final_activation != 'sigmoid'")
+            probs, _, _ = self._fwd_train.decoder_training_mode(x, y0)
+            return DeviceArray(probs)
         if self._kind == 'encoder':
             return DeviceArray(self._engine.forward(x))
         z_act = x if self._engine.dt == _lib.VV_F32 else x.to(torch.bfloat16)

@@ -1,6 +1,8 @@
 """Entry point with the role of the reference's test_modelnet_VAE.py (loop :104-156, printed fields :141-150, config
 :169-192): one epoch of getEval over the test split with missing-latent correction.
-`python test_modelnet_VAE.py --voxel 32 --batch 256 --dtype bf16 --missing-pr 0.9 [--device-data]`."""
+`python test_modelnet_VAE.py --voxel 32 --batch 256 --dtype bf16 --missing-pr 0.9 [--device-data] [--dump-dir DIR]`.
+--dump-dir writes the three arrays the reference collects per batch (:128-130) and saves at the end of the epoch (:159-165, the
+input of the notebooks' precision / recall tool): `<missing_pr>_cl_label.npy`, `<missing_pr>_gt.npy`, `<missing_pr>_pred.npy`."""
 import os
 import sys
 
@@ -13,9 +15,17 @@ from src.dataset_loader.modelnet_dataset import dataLoader, deviceDataLoader
 FIELDS = ('loss', 'pr', 'rc', 'c'), ('closs', 'cpr', 'crc', 'cc')
 
 
-def evaluate(model, loader, missing_pr, batch_size, max_iter, class_key='class_list', **extra):
-    """The shared test loop: getEval over one epoch, running means of the 8 reported numbers."""
+def _host(a):
+    """np.array() of a batch member: host arrays as they are, device-resident batches (--device-data) copied back."""
+    return a.detach().cpu().numpy() if hasattr(a, 'detach') else np.array(a)
+
+
+def evaluate(model, loader, missing_pr, batch_size, max_iter, class_key='class_list', dump_dir=None, **extra):
+    """The shared test loop: getEval over one epoch, running means of the 8 reported numbers.
+    dump_dir: also keep every batch's labels, targets and predictions and save them as the reference's
+    `<missing_pr>_cl_label.npy / _gt.npy / _pred.npy` (test_modelnet_VAE.py:128-130, 159-165)."""
     means = C.RunningMeans(eval=8)
+    labels, gts, preds = [], [], []
     bar = C.Progress(width=5)
     print('start training...')
     for epoch, position, total in C.epochs_of(loader, 1, 'batchStart'):
@@ -24,6 +34,10 @@ def evaluate(model, loader, missing_pr, batch_size, max_iter, class_key='class_l
         x = batch['input_images']
         out = model.getEval(inputs=(x, x, batch[class_key]), missing_prob=missing_pr, **extra)
         means.add(eval=out[1:5] + out[6:10])
+        if dump_dir is not None:
+            labels.append(_host(batch[class_key]))
+            gts.append(_host(x))
+            preds.append(_host(out[0]))
         bar.toc()
         m = means['eval']
         bar.show(epoch, position, total, bar.group(zip(FIELDS[0], m[:4])) + ",", bar.group(zip(FIELDS[1], m[4:])))
@@ -32,6 +46,10 @@ def evaluate(model, loader, missing_pr, batch_size, max_iter, class_key='class_l
         if max_iter is not None and means.n >= max_iter:
             break
     print('')
+    if dump_dir is not None and labels:
+        os.makedirs(dump_dir, exist_ok=True)
+        for suffix, parts in (('_cl_label.npy', labels), ('_gt.npy', gts), ('_pred.npy', preds)):
+            np.save(os.path.join(dump_dir, str(missing_pr) + suffix), np.concatenate(parts, axis=0))
     return means['eval']
 
 
@@ -41,7 +59,7 @@ def train(
         config=None, dataset_path=None,
         save_path=None, load_path=None,
         missing_pr=0.3,
-        learn='train', batch_size=72, max_iter=None, model_class='VAE', device_data=False,
+        learn='train', batch_size=72, max_iter=None, model_class='VAE', device_data=False, dump_dir=None,
 ):
     import src.module.nolbo as nolbo
     cls = nolbo.nolboSingleObject_modelnet_category_VAE if model_class == 'VAE' else nolbo.nolboSingleObject_modelnet_category_AE
@@ -60,7 +78,7 @@ def train(
     if category_vectors is None:                                  # no prototypes on disk: seeded stand-ins
         from voxvae import synthetic as syn
         category_vectors = syn.make_category_vectors(40, config['z_category_dim'])
-    return evaluate(model, loader, missing_pr, batch_size, max_iter, category_vectors=category_vectors)
+    return evaluate(model, loader, missing_pr, batch_size, max_iter, dump_dir=dump_dir, category_vectors=category_vectors)
 
 
 latent_dim = 64
@@ -72,4 +90,5 @@ if __name__ == '__main__':
     sys.exit(0 if train(
         learning_rate=a.lr, config=C.make_config(a.latent, a.voxel, True), dataset_path=a.dataset_path,
         load_path=a.load_path, missing_pr=a.missing_pr, batch_size=a.batch, max_iter=a.max_iter, device_data=a.device_data,
+        dump_dir=a.dump_dir,
     ) is not None else 1)

@@ -1,9 +1,11 @@
 """One evaluation step as a HIP graph.
 
-At small batches the 13 launches of a step are bound by the host (ctypes call + argument marshalling per launch: config 1 of
-BASELINE.json, batch 4, takes 0.24 ms per step of which the GPU is busy a fraction).  Capturing the step once and replaying the
-graph removes the per-launch host work: the kernels, their arguments and the buffers they use are frozen in the graph, the
-caller writes the next batch into the graph's input tensors.
+Capturing the step once and replaying the graph removes the per-launch host work (ctypes call + argument marshalling): the
+kernels, their arguments and the buffers they use are frozen in the graph, the caller writes the next batch into the graph's
+input tensors.  MEASURED (MI355X): it buys nothing on this path -- at batch 4 a step takes 0.241 ms launched
+call by call and 0.245 ms replayed, at batch 256 0.633 vs 0.647 ms: the launches are queued ahead of the GPU, and a step costs the
+dependency latency of its launches, not host time.  bench.py times the eager path; this class exists for callers whose host thread
+is busy elsewhere and as the capturability test of the step (no allocation, no host sync, no stream switch inside it).
 
     g = GraphedEvalStep(model, x, y, eps)      # captures model.eval_forward_device(x, y, eps) after a few warm-up calls
     pred, stats, metrics, kl = g(x_next, y_next, eps_next)     # copies the inputs in, replays, returns the graph's outputs
@@ -39,6 +41,9 @@ class GraphedEvalStep:
         """Copy the given inputs into the graph's input tensors (None = keep what is there), replay, return the outputs."""
         if x is not None:
             self.x.copy_(x, non_blocking=True)
+        if y is not None and self.same and not (y is x or (x is not None and y.data_ptr() == x.data_ptr())):
+            raise ValueError('this graph was captured with the input as its own target (y is x): a different target needs a graph '
+                             'captured with a separate y tensor')
         if y is not None and not self.same:
             self.y.copy_(y, non_blocking=True)
         if eps is not None and self.eps is not None:

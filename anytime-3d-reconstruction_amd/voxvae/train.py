@@ -56,12 +56,29 @@ class GradBuckets:
             for name, shape, n, off in items:
                 self.views[name] = buf[off:off + n].view(*shape)
                 self.bucket_of[name] = len(self.buckets) - 1
+        self.always_reduce = False   # True: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)
+        self.profile = None          # a list: finish() appends (event before, event after) -- the EXPOSED collective time
         self.begin_step()
 
-    @staticmethod
-    def _distributed(group):
+    def _distributed(self, group):
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.always_reduce)
+
+    def blocking_all_reduce_ms(self, group=None, repeats=5):
+        """Calibration for the overlap report: every bucket all-reduced back to back with nothing else on the device, in ms
+        per step's worth of buckets (the buckets are left multiplied by world^repeats: call it outside a training step)."""
+        import torch.distributed as dist
+        if not self._distributed(group):
+            return 0.0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(repeats):
+            for b in self.buckets:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / repeats
 
     def all_reduce(self, group=None):
         """Sum every bucket across the ranks (blocking form: all launched together, then waited)."""
@@ -93,12 +110,19 @@ class GradBuckets:
             self._works[b] = False
 
     def finish(self, group=None):
+        prof = self.profile is not None and self.buckets[0].is_cuda
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                   # the backward kernels are all enqueued: whatever the waits below add is exposed
         for b in range(len(self.buckets)):
             if self._works[b] is None:
                 self._launch(b, group)
         for w in self._works:
             if w:
                 w.wait()
+        if prof:
+            e1.record()
+            self.profile.append((e0, e1))
 
 
 class _BN:
@@ -135,6 +159,33 @@ class Trainer:
         self.grads = GradBuckets(self.order, self.dev)
         self.m = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
         self.v = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
+
+    @classmethod
+    def forward_only(cls, enc=None, dec=None):
+        """A Trainer without gradient / optimiser state: the training-mode forward of ONE sub-model (the builder-level
+        `model(x, training=True)`, reference nolbo.py:1426 / AE3D.py:72-73)."""
+        eng = dec if dec is not None else enc
+        if eng.fp8:
+            raise ValueError("training=True runs in 'f32' or 'bf16'; 'fp8' is an inference mode")
+        t = cls.__new__(cls)
+        t.enc, t.dec, t.dt = enc, dec, eng.dt
+        t.tdt = torch.bfloat16 if t.dt == L.VV_BF16 else torch.float32
+        t.dev, t.ws, t.debug, t.var = eng.device, E._Workspace(eng.device), None, False
+        return t
+
+    def _moved_statistics(self, *engines):
+        """The moving statistics were updated in place by a training-mode forward: the folded inference scale / shift
+        vectors of these engines are stale (the weight images are not)."""
+        for e in engines:
+            if e is not None:
+                e._folded = False
+
+    def encoder_training_mode(self, x):
+        """encoder(x, training=True): batch-statistics BatchNorm, moving statistics move; -> enc_out float32 [B, E]."""
+        self.enc.ensure_packed(fold=False)
+        enc_out, _ = self._encoder_forward(x, x.shape[0])
+        self._moved_statistics(self.enc)
+        return enc_out
 
     # ------------------------------------------------------------------ helpers
     def _p(self, name):
@@ -357,12 +408,14 @@ class Trainer:
             z = z_fn(z)
             z_act = self._cast(z)
         fw = self._decoder_forward(z_act, y, B)
+        self._moved_statistics(self.enc, self.dec)
         return z, kl, fw['probs'], fw['stats'], fw['metrics']
 
     def decoder_training_mode(self, z, y):
         """Decoder half of forward_training_mode for an edited latent (the corrected pass of getEval)."""
         self.dec.ensure_packed(fold=False)
         fw = self._decoder_forward(self._cast(z), y, z.shape[0])
+        self._moved_statistics(self.dec)
         return fw['probs'], fw['stats'], fw['metrics']
 
     def _latent_decoder(self, enc_out, y, eps, drop_mask, drop_scale, B, inv_gb):

@@ -184,6 +184,59 @@ def parity_against(ref, logits, stats, guard=1e-4):
             'max_abs_ref_logit_at_a_flip': float(np.abs(rl[flip]).max()) if flip.any() else 0.0}
 
 
+def baseline_config_label(a):
+    """Which BASELINE.json config the command line is (or is the per-GPU geometry of), so that a 64^3 / fp8 line is not
+    labelled as the headline config."""
+    if a.voxel == 32 and a.batch == 256 and a.dtype == 'bf16':
+        return 'BASELINE.json configs[1]'
+    if a.voxel == 64 and a.dtype == 'fp8':
+        return "the per-GPU shard geometry of BASELINE.json configs[4] (64^3, fp8 MFMA; 512 over 8 GPUs = 64 per GPU)" + \
+            ('' if a.batch == 64 else ', at batch %d' % a.batch)
+    return 'not a BASELINE.json config as such: configs[1] geometry varied (voxel %d, batch %d, dtype %s)' % (a.voxel, a.batch, a.dtype)
+
+
+def trained_parity(a, dev, build_model):
+    """parity.trained: the same comparison at a TRAINED operating point.  The 32^3 VAE is fitted with the repo's own float32
+    fit() (voxvae/trained.py; ~10 s) until it reconstructs its synthetic shapes and its logits pass the +-15.94 clip of
+    function.py:79; the trained weights go to the C oracle and to the HIP path in this run's dtype and in f32.  Outside the
+    timed region."""
+    import voxvae
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    from voxvae import trained as tr
+    t0 = time.perf_counter()
+    cfg_t, ep_t, dp_t, info = tr.train_operating_point(voxel=a.voxel, latent=a.latent, device=dev)
+    t_fit = time.perf_counter() - t0
+    n = 64
+    xh = np.concatenate([syn.make_voxels(256, a.voxel, seed=4321)[:48], syn.make_voxels(16, a.voxel, seed=777)], axis=0)
+    epsh = syn.make_eps(n, a.latent, seed=70)
+    ref = co.vae_eval_forward(cfg_t, ep_t, dp_t, xh, xh, epsh)
+    iou_c = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
+    x, eps = torch.from_numpy(xh).to(dev), torch.from_numpy(epsh).to(dev)
+    out = {'fit_steps': info['steps'], 'fit_seconds': t_fit, 'fit_dtype': 'f32', 'reached': bool(info['reached']), 'samples': n,
+           'iou_ref': float(iou_c.mean()), 'max_abs_ref_logit': float(np.abs(ref['logits']).max()),
+           'fraction_of_voxels_beyond_the_clip': float(np.mean(np.abs(ref['logits']) > 15.94)),
+           'what': '32^3 VAE fitted by fit() on 256 seeded synthetic shapes; 48 seen + 16 unseen shapes evaluated; oracle = fp32 C restatement'}
+    for dt in dict.fromkeys([a.dtype, 'f32']):
+        voxvae.set_default_dtype(dt)
+        m = build_model(True, cfg_t, ep_t, dp_t)
+        voxvae.set_default_dtype(a.dtype)
+        _, z_act, _ = m._encode_latent(x, eps)
+        _, lg, st_ = m._dec_eng.forward(z_act, x, want_logits=True)
+        p = parity_against(ref, lg.cpu().numpy(), st_.cpu().numpy())
+        bce_rel = float(np.max(np.abs(st_.cpu().numpy()[:, 0].astype(np.float64) - ref['bce']) / ref['bce']))
+        d = {'iou_delta': p['iou_delta'], 'max_per_sample_iou_delta': p['max_per_sample_iou_delta'], 'max_logit_err': p['max_logit_err'],
+             'flips': p['occupancy_flips'], 'flips_outside_guard_band': p['occupancy_flips_outside_guard_band'],
+             'max_abs_ref_logit_at_a_flip': p['max_abs_ref_logit_at_a_flip'], 'max_rel_bce_err_per_sample': bce_rel}
+        if dt == a.dtype:
+            out.update(d)
+            out['dtype'] = dt
+        if dt == 'f32':
+            out['f32_mode'] = d
+        del m
+    return out
+
+
 def time_steps(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -200,6 +253,8 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
     """Training-step throughput (BASELINE.json configs[3]: batch sharded over the ranks, gradients summed by RCCL)."""
     from voxvae import train as T
     tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-4, world_size=world)
+    # Under a launcher the gradient buckets always go through RCCL, also with one rank (same code path as N > 1)
+    tr.grads.always_reduce = dist is not None
     for _ in range(a.warmup):
         tr.step(x, x, eps)
     if dist is not None:
@@ -213,6 +268,22 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
         dist.barrier()
     el = time.perf_counter() - t0
     sums, el, nranks = reduce_metrics(dist, metric_vector(stats, kl), el, dev)
+    # how much of the gradient all-reduce hides under the backward pass: exposed = what finish() still waits for after the last
+    # backward kernel (events on the launch stream, 10 extra steps outside the timed region), total = the same buckets
+    # all-reduced back to back on an otherwise idle device
+    overlap = None
+    if dist is not None:
+        tr.grads.profile = []
+        for _ in range(10):
+            tr.step(x, x, eps)
+        torch.cuda.synchronize()
+        exposed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in tr.grads.profile]))
+        tr.grads.profile = None
+        total = tr.grads.blocking_all_reduce_ms()
+        overlap = {'buckets': len(tr.grads.buckets), 'bucket_bytes': [int(b.numel() * 4) for b in tr.grads.buckets],
+                   'all_reduce_ms_back_to_back': total, 'exposed_ms_after_backward': exposed,
+                   'overlapped_fraction': (max(0.0, 1.0 - exposed / total) if total > 0 else None),
+                   'launch_order': list(tr.grads.launch_order)}
     if rank == 0:
         print(json.dumps({'metric': '32^3 voxel VAE training samples/sec (fit: fwd + bwd + Adam)', 'value': world * a.batch * a.steps / el,
                           'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el / a.steps,
@@ -220,7 +291,8 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
                           'config': {'workload': 'ModelNet40 VAE fit(), %d^3 voxels, latent %d, batch %d per GPU (BASELINE.json configs[3])'
                                                  % (a.voxel, a.latent, a.batch), 'global_batch': a.batch * world,
                                      'parallelism': 'dp%d, bucketed RCCL all-reduce of gradients, per-rank BatchNorm' % world},
-                          'rccl_world_size': nranks, 'global_metrics': global_metrics(sums),
+                          'rccl_world_size': nranks, 'process_group': dist.get_backend() if dist is not None else None,
+                          'global_metrics': global_metrics(sums), 'gradient_all_reduce': overlap,
                           'final_loss_shape': float(metrics[0]), 'final_loss_kl': float(kl.mean())}))
     if dist is not None:
         dist.destroy_process_group()
@@ -368,8 +440,10 @@ def main():
 
     # ---- parity gate + CPU baseline + secondary legs (rank 0, N == 1 only): AFTER the timed region -- the oracle's OpenMP
     # team spin-waits on every host core and would starve the launch thread
-    cpu, cpu_torch, parity, f32_leg, h2d, cfg1 = None, None, None, None, None, None
+    cpu, cpu_torch, parity, f32_leg, h2d, cfg1, trained = None, None, None, None, None, None, None
     if rank == 0 and world == 1 and a.cpu_samples > 0:
+        if a.voxel == 32:
+            trained = trained_parity(a, dev, build_model)
         ref, cpu = cpu_baseline(cfg, ep, dp, xh, epsh, a.cpu_samples)
         cpu_torch = cpu_baseline_torch(cfg, ep, dp, xh, epsh, ref)
         n = ref['bce'].shape[0]
@@ -491,17 +565,18 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'ModelNet40 VAE getEval(missing_prob=0), %d^3 voxels, latent %d, batch %d per GPU, '
-                                   'encoder+reparam/KL+decoder+BCE/TP/FP/FN (BASELINE.json configs[1])' % (a.voxel, a.latent, a.batch),
+                                   'encoder+reparam/KL+decoder+BCE/TP/FP/FN (%s)' % (a.voxel, a.latent, a.batch, baseline_config_label(a)),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world,
                        'parallelism': 'batch-sharded x%d, no data-path collective; 8 metric scalars all-reduced once' % world,
                        'streams_per_gpu': nstreams,
                        'scheduling': ('independent 256-batches issued round-robin on %d HIP streams, one engine replica (weights + workspaces) per stream' % nstreams)
                                      if nstreams > 1 else 'one batch at a time on one stream'},
-            'rccl_world_size': nranks, 'global_metrics': global_metrics(sums),
+            'rccl_world_size': nranks, 'process_group': dist.get_backend() if dist is not None else None,
+            'global_metrics': global_metrics(sums),
             'iou_delta': None if parity is None else parity['iou_delta'],
             'max_logit_err_vs_cpu_oracle': None if parity is None else parity['max_logit_err'],
             'parity': None if parity is None else dict(parity, oracle='fp32 C restatement (parity unpinned: the reference holds no golden vectors and TensorFlow is absent)',
-                                                       f32_mode=f32_leg),
+                                                       f32_mode=f32_leg, trained=trained),
             'whole_path': {'algorithmic_flops_per_reconstruction': fl_rec, 'dense_flops_per_reconstruction': fl_dense,
                            'achieved_TFLOPs_per_gpu': fl_rec * a.batch * a.steps * world / el / world / 1e12,
                            'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},

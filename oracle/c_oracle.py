@@ -141,3 +141,34 @@ def vae_eval_forward(config, enc_p, dec_p, x, y, eps, variational=True):
     probs, bce, tp, fp, fn = sigmoid_bce_counts(logits, y)
     return {'enc_out': enc_out, 'z': z, 'kl': kl, 'logits': logits, 'probs': probs, 'bce': bce, 'tp': tp, 'fp': fp,
             'fn': fn}
+
+
+def vae_get_eval(config, enc_p, dec_p, x, y, onehot, category_vectors, eps, missing_prob, mask, eps2):
+    """getEval with missing latents -- nolbo.py:1449-1528 -- composed from the fp32 C pieces above (both decoder passes) and
+    the [B, L] latent algebra in float32 numpy (the reference's arithmetic type): the form the trained-weights parity test
+    uses at batch sizes where the float64 definition-level oracle (numpy_oracle.vae_get_eval) takes minutes.
+    Returns a dict: first pass `logits, probs, bce, tp, fp, fn, z, acc`, corrected pass the same keys with suffix `_c`."""
+    from . import numpy_oracle as no
+    L = config['z_category_dim']
+    cats = _f32(category_vectors)
+    enc_out = encoder3D_forward(config['encoder'], enc_p, x)
+    z, _ = reparam_kl(enc_out, eps, L)                                       # :1464-1470
+    m = _f32(mask)
+    if missing_prob > 0:
+        z = z * m                                                            # :1477
+        z = np.where(z == 0, cats.mean(axis=0, dtype=np.float32)[None, :] * np.ones_like(z), z).astype(np.float32)   # :1481-1482
+    _, acc = no._nearest_category_acc(z, cats, onehot)
+    logits = decoder3D_logits(config['decoder'], dec_p, z)
+    probs, bce, tp, fp, fn = sigmoid_bce_counts(logits, y)
+    out = {'z': z, 'acc': acc, 'logits': logits, 'probs': probs, 'bce': bce, 'tp': tp, 'fp': fp, 'fn': fn}
+    if missing_prob == 0:
+        return out
+    idx, _ = no._nearest_category_acc(z, cats, onehot, mask=m)               # :1505-1506
+    z_prior = (cats[idx] + _f32(eps2)).astype(np.float32)                     # sampling(mu, logVar = 0): sqrt(exp(0)) = 1 (:1507-1509)
+    z_corr = np.where(m == 0, z_prior, z).astype(np.float32)                 # :1510
+    _, acc_c = no._nearest_category_acc(z_corr, cats, onehot)
+    logits_c = decoder3D_logits(config['decoder'], dec_p, z_corr)
+    probs_c, bce_c, tp_c, fp_c, fn_c = sigmoid_bce_counts(logits_c, y)
+    out.update({'z_c': z_corr, 'acc_c': acc_c, 'logits_c': logits_c, 'probs_c': probs_c, 'bce_c': bce_c, 'tp_c': tp_c,
+                'fp_c': fp_c, 'fn_c': fn_c, 'argmin_masked': idx})
+    return out

@@ -56,7 +56,7 @@ def _bn_train(x, gamma, beta, stats, name):
     return gamma * (x - m) / torch.sqrt(v + BN_EPS) + beta
 
 
-def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_scale=1.0, latent_fn=None):
+def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_scale=1.0, latent_fn=None, aux=None):
     """P: dict name -> torch tensor ('enc/...' and 'dec/...').  Returns (loss_kl, loss_shape, probs, stats).
     latent_fn(enc_out) -> (z_input, extra_loss): replaces the built-in latent algebra (the class-conditional prior model,
     reference nolbo.py:1620-1676); `loss_kl` is then extra_loss."""
@@ -80,6 +80,8 @@ def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_s
         z, kl = e, torch.zeros((), dtype=torch.float64)
     if drop_mask is not None:
         z = z * drop_mask * drop_scale
+    if aux is not None:                      # the encoder output and the decoder input, for the builder-level model(x, training=True) tests
+        aux['enc_out'], aux['z'] = e.detach().numpy().copy(), z.detach().numpy().copy()
     side = dec['output_shape'][0] // int(np.prod(dec['strides_list']))
     ch = max(dec['filter_num_list'][0] // 64, 8)
     t = z @ P['dec/dense/kernel'] + P['dec/dense/bias']
@@ -116,8 +118,9 @@ def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variatio
         P['enc/' + k] = _t(v, grad=not k.endswith(('moving_mean', 'moving_variance')))
     for k, v in dec_p.items():
         P['dec/' + k] = _t(v, grad=not k.endswith(('moving_mean', 'moving_variance')))
+    aux = {}
     kl, shape, p, stats = forward_train(config, P, _t(x), _t(y), _t(eps), variational,
-                                        None if drop_mask is None else _t(drop_mask), drop_scale)
+                                        None if drop_mask is None else _t(drop_mask), drop_scale, aux=aux)
     total = kl + shape if variational else shape       # nolbo.py:1436 / 1247
     names = trainable_names(P)
     if not variational:
@@ -146,7 +149,7 @@ def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variatio
     fn = (yn * (1 - yh)).reshape(B, -1).sum(-1)
     return {'loss_kl': float(kl.detach()), 'loss_shape': float(shape.detach()), 'pr': float(np.mean(tp / (tp + fp + 1e-10))),
             'rc': float(np.mean(tp / (tp + fn + 1e-10))), 'grads': g, 'params': new, 'bn_stats': stats,
-            'adam': {'t': t, 'm': m2, 'v': v2}, 'probs': pn}
+            'adam': {'t': t, 'm': m2, 'v': v2}, 'probs': pn, 'enc_out': aux['enc_out'], 'z': aux['z']}
 
 
 def fit_step_category_only(config, enc_p, dec_p, mean_prior, logvar_prior, x, y, eps, eps_prior, noise=None, drop_keep=None,

@@ -59,7 +59,7 @@ def test_fit_step_matches_autograd_oracle(D, Lz, var, B):
             assert np.abs(g).max() <= 64 * np.finfo(np.float32).eps * B * scale, (np.abs(g).max(), scale)
             continue
         worst[name] = _rel(g, ref['grads'][name])
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    bad = {k: v for k, v in worst.items() if v > 5e-5}
     assert not bad, 'gradient mismatch (max rel err): %s' % bad
     new_e, new_d = model._encoder.get_weights_dict(), model._decoder.get_weights_dict()
     for k, v in list(new_e.items()) + list(new_d.items()):
@@ -246,7 +246,7 @@ def test_fit_step_with_latent_dropout_matches_autograd_oracle():
         if name == 'dec/dense/bias':
             continue
         worst[name] = _rel(tr.grads.views[name].cpu().numpy(), ref['grads'][name])
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    bad = {k: v for k, v in worst.items() if v > 5e-5}
     assert not bad, 'gradient mismatch with latent dropout (max rel err): %s' % bad
     # the encoder's gradients flow only through the kept latent entries: a wrong mask in the backward would show here first
     assert worst['enc/conv4/kernel'] < 2e-3
@@ -281,6 +281,101 @@ def test_getEval_training_true_uses_batch_statistics_and_moves_the_moving_ones()
     out3 = model.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.5, _eps=eps, _mask=mask,
                          _eps2=syn.make_eps(6, 64, seed=5))
     assert len(out3) == 10 and all(np.isfinite(float(v)) for v in out3[1:5] + out3[6:10])
+
+
+def test_eval_after_training_mode_forward_uses_the_moved_statistics():
+    """eval -> getEval(training=True) -> eval: the second evaluation must fold the MOVED moving statistics (reference
+    nolbo.py:1463 / 1496 read them live).  The engines keep folded scale / shift vectors; a training-mode forward moves
+    the statistics in place without touching a weight, so the fold has to be redone (round-2 advisor finding)."""
+    from oracle import c_oracle as co
+    from oracle import torch_oracle as to
+    from voxvae import synthetic as syn
+    cfg, ep, dp, model, x, eps = _setup(16, 64, True, 6, seed=2)
+    oh, cats = syn.make_onehot(6, 40), syn.make_category_vectors(40, 64)
+    xd, epsd = torch.from_numpy(x).to(DEV), torch.from_numpy(eps).to(DEV)
+    p0, _, _, _ = model.eval_forward_device(xd, xd, epsd)                       # folds the ORIGINAL statistics
+    p0 = p0.cpu().numpy()
+    np.testing.assert_allclose(p0, co.vae_eval_forward(cfg, ep, dp, x, x, eps)['probs'], atol=2.5e-4)
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=True)       # its 'params' hold the moved statistics
+    model.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.0, _eps=eps)
+    moved_e = {k: (ref['params']['enc/' + k] if k.endswith(('moving_mean', 'moving_variance')) else v) for k, v in ep.items()}
+    moved_d = {k: (ref['params']['dec/' + k] if k.endswith(('moving_mean', 'moving_variance')) else v) for k, v in dp.items()}
+    want = co.vae_eval_forward(cfg, moved_e, moved_d, x, x, eps)['probs']
+    p1, _, _, _ = model.eval_forward_device(xd, xd, epsd)
+    p1 = p1.cpu().numpy()
+    assert np.abs(want - p0).max() > 1e-3                                      # the statistics moved enough to matter
+    np.testing.assert_allclose(p1, want, atol=2.5e-4)
+    # decoder-only training-mode pass (the corrected pass of getEval) marks the decoder's fold stale too
+    model._train_helper().decoder_training_mode(torch.from_numpy(eps).to(DEV), xd)
+    assert not model._dec_eng._folded and model._enc_eng._folded
+
+
+def test_builder_level_models_called_with_training_true():
+    """`model(x, training=True)` on what encoder3D / decoder3D return (reference callers: nolbo.py:1426
+    `self._decoder(z, training=True)`, AE3D.py:72-73): batch-statistics BatchNorm, moving statistics move, weights do not."""
+    from oracle import torch_oracle as to
+    cfg, ep, dp, model, x, eps = _setup(16, 64, True, 6, seed=2)
+    ref = to.fit_step(cfg, ep, dp, x, x, eps, lr=1e-3, variational=True)
+    enc_out = np.array(model._encoder(x, training=True))
+    np.testing.assert_allclose(enc_out, ref['enc_out'], rtol=0, atol=2e-5)
+    z = np.array(model._encoder(x, training=False))                            # inference call still works, on the moved statistics
+    assert z.shape == enc_out.shape and np.abs(z - enc_out).max() > 1e-4
+    probs = np.array(model._decoder(ref['z'].astype(np.float32), training=True))
+    np.testing.assert_allclose(probs, ref['probs'], rtol=0, atol=2e-5)
+    new_e, new_d = model._encoder.get_weights_dict(), model._decoder.get_weights_dict()
+    for pre, new, old in (('enc/', new_e, ep), ('dec/', new_d, dp)):
+        for k, v in new.items():
+            if k.endswith(('moving_mean', 'moving_variance')):
+                np.testing.assert_allclose(v, ref['params'][pre + k], rtol=1e-4, atol=1e-6, err_msg=pre + k)
+            else:
+                np.testing.assert_array_equal(v, old[k], err_msg=pre + k)
+
+
+def test_legacy_two_input_getEval_training_true_applies_the_zero_mask():
+    """getEval((x, y), training=True, missing_prob > 0): the legacy body (nolbo.py:1544-1548) zeroes the masked latent
+    entries; in training mode that must happen too (it used to be ignored)."""
+    cfg, ep, dp, model, x, eps = _setup(16, 64, True, 6, seed=2)
+    mask = (np.random.default_rng(1).random((6, 64)) >= 0.5).astype(np.float32)
+    a = model.getEval(inputs=(x, x), training=True, missing_prob=0.5, _eps=eps, _mask=mask)
+    b = model.getEval(inputs=(x, x), training=True, missing_prob=0.0, _eps=eps)
+    ones = model.getEval(inputs=(x, x), training=True, missing_prob=0.5, _eps=eps, _mask=np.ones_like(mask))
+    assert len(a) == 4 and np.abs(np.array(a[0]) - np.array(b[0])).max() > 1e-3     # the mask changes the prediction
+    # an all-ones mask is no mask; the moving statistics moved between the two calls but the batch statistics rule here
+    np.testing.assert_allclose(np.array(ones[0]), np.array(b[0]), atol=1e-6)
+
+
+def test_class_conditional_prior_getEval_training_true():
+    """nolbo.py:1678-1754 passes `training` to the prior network, the encoder and the decoder: with training=True the result
+    is the VAE class's training-mode getEval against the prior means (the prior net's own BatchNorm / Dropout in training
+    mode are torch modules; its means are read back and injected on the comparison side)."""
+    import voxvae
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('f32')
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    import src.net_core.priornet as priornet
+    D, Lz, B = 16, 64, 6
+    cfg = syn.make_config(D, Lz, True)
+    cfg['prior_class'] = dict(priornet.priornet_structure, unit_num_list=[64, 32, Lz])
+    ep = syn.make_encoder_params(cfg['encoder'], seed=42, nontrivial_affine=True)
+    dp = syn.make_decoder_params(cfg['decoder'], seed=43, nontrivial_affine=True, final_gain=2.0)
+    x, eps, oh = syn.make_voxels(B, D, seed=102), syn.make_eps(B, Lz, seed=202), syn.make_onehot(B, 40)
+    outs = []
+    for cls in (nolbo.nolboSingleObject_modelnet_category_only, nolbo.nolboSingleObject_modelnet_category_VAE):
+        m = cls(nolbo_structure=cfg, learning_rate=1e-3)
+        m._encoder.set_weights_dict(ep)
+        m._decoder.set_weights_dict(dp)
+        if cls is nolbo.nolboSingleObject_modelnet_category_only:
+            torch.manual_seed(5)
+            o = m.getEval(inputs=(x, x, oh), training=True, missing_prob=0.0, _eps=eps)
+            torch.manual_seed(5)                                                # same Dropout draw -> the prior means it used
+            cats, _ = m._priornet_class(np.identity(40, dtype='float32'), training=True)
+            cats = cats.detach().cpu().numpy()
+        else:
+            o = m.getEval(inputs=(x, x, oh), category_vectors=cats, training=True, missing_prob=0.0, _eps=eps)
+        outs.append(o)
+    np.testing.assert_array_equal(np.array(outs[0][0]), np.array(outs[1][0]))
+    assert [float(v) for v in outs[0][1:5]] == [float(v) for v in outs[1][1:5]]
 
 
 def test_class_conditional_prior_fit_matches_autograd_oracle():
@@ -342,7 +437,120 @@ def test_class_conditional_prior_fit_matches_autograd_oracle():
             if name == 'dec/dense/bias':
                 continue
             worst[name] = _rel(tr.grads.views[name].cpu().numpy(), ref['grads'][name])
-        bad = {k: v for k, v in worst.items() if v > 2e-3}
+        bad = {k: v for k, v in worst.items() if v > 5e-5}
         assert not bad, 'gradient mismatch (mix=%s): %s' % (mix, bad)
         assert _rel(stub.m.grad.cpu().numpy(), ref['grad_mean_prior']) < 1e-3
         assert _rel(stub.lv.grad.cpu().numpy(), ref['grad_logvar_prior']) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- config 4's per-rank shape: B = 256
+def _grads_of_step(dtype, x, eps, lr=1e-3):
+    """One Trainer.step at batch len(x) from the seeded weights -> ({name: gradient}, stats, kl, moving statistics)."""
+    from voxvae import train as T
+    cfg, ep, dp, model, _, _ = _setup(32, 64, True, 2, dtype=dtype)
+    tr = T.Trainer(model._enc_eng, model._dec_eng, True, lr)
+    xd, ed = torch.from_numpy(x).to(DEV), torch.from_numpy(eps).to(DEV)
+    kl, stats, metrics = tr.step(xd, xd, ed)
+    torch.cuda.synchronize()
+    g = {n: tr.grads.views[n].clone() for n, _ in tr.order}
+    mov = {k: v.clone() for k, v in list(model._enc_eng.params.items()) + list(model._dec_eng.params.items())
+           if k.endswith(('moving_mean', 'moving_variance'))}
+    return g, stats.clone(), kl.clone(), mov
+
+
+def _rel_max(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_fit_at_batch_256_replication_and_permutation(dtype):
+    """BASELINE config 4 runs 256 samples per rank; the float64 autograd oracle stops at batch 4-6.  Two exact properties
+    carry the oracle-checked small-batch step to the full batch, through every kernel form that only runs at large batches
+    (sweep-form last layer, whole-sample D4, phase-form weight gradients, 1024-way split single-channel weight gradients):
+
+    * replication: a 256-batch made of 16 copies of a 16-batch has the same batch statistics (mean, biased variance), the
+      same per-sample activations and, with the loss averaged over the batch, the SAME gradients as the 16-batch step --
+      BatchNorm's backward included (its batch sums grow 16x, its 1/B shrinks 16x);
+    * permutation: re-ordering the samples of a batch of 256 DISTINCT samples changes no gradient (replication alone could
+      not see a kernel that reads a neighbour's sample).
+
+    Gates: float32 5e-5 of the tensor's max (summation order only); bf16 mixed precision 2e-2 (a different summation order moves
+    batch statistics in the last float32 bit, which re-rounds bf16 activations downstream)."""
+    from voxvae import synthetic as syn
+    gate = 5e-5 if dtype == 'f32' else 2e-2
+    x16, e16 = syn.make_voxels(16, 32, seed=611), syn.make_eps(16, 64, seed=612)
+    g16, st16, kl16, mov16 = _grads_of_step(dtype, x16, e16)
+    x256, e256 = np.tile(x16, (16, 1, 1, 1, 1)), np.tile(e16, (16, 1))
+    g256, st256, kl256, mov256 = _grads_of_step(dtype, x256, e256)
+    worst = {n: _rel_max(g256[n], g16[n]) for n in g16 if n != 'dec/dense/bias'}
+    print('\n[fit B=256 %s] replication: worst gradient rel err %.2e (%s)' % (dtype, max(worst.values()), max(worst, key=worst.get)))
+    assert max(worst.values()) <= gate, {k: v for k, v in worst.items() if v > gate}
+    # per-sample losses / counts repeat with period 16, moving statistics agree
+    srel = (st256.view(16, 16, 4) - st16[None]).abs().max() / st16.abs().max()
+    assert float(srel) <= (1e-5 if dtype == 'f32' else 2e-2)
+    assert float((kl256.view(16, 16) - kl16[None]).abs().max()) <= 1e-3 * float(kl16.abs().max())
+    for k in mov16:
+        assert _rel_max(mov256[k], mov16[k]) <= (1e-5 if dtype == 'f32' else 1e-3), k
+    # permutation at 256 distinct samples
+    xd, ed = syn.make_voxels(256, 32, seed=613), syn.make_eps(256, 64, seed=614)
+    perm = np.random.default_rng(615).permutation(256)
+    ga, sta, _, _ = _grads_of_step(dtype, xd, ed)
+    gb, stb, _, _ = _grads_of_step(dtype, xd[perm], ed[perm])
+    worst = {n: _rel_max(gb[n], ga[n]) for n in ga if n != 'dec/dense/bias'}
+    print('[fit B=256 %s] permutation: worst gradient rel err %.2e (%s)' % (dtype, max(worst.values()), max(worst, key=worst.get)))
+    assert max(worst.values()) <= gate, {k: v for k, v in worst.items() if v > gate}
+    assert float((stb - sta[torch.from_numpy(perm).to(DEV)]).abs().max() / sta.abs().max()) <= (1e-5 if dtype == 'f32' else 2e-2)
+
+
+def _wgrad_ref_gpu_f64(src, g):
+    """The definition of tests/test_gpu_ops._wgrad_conv_ref evaluated in float64 by torch ON THE GPU (a checker, not the
+    product: slicing + one matmul per tap); the numpy loop takes minutes at batch 256."""
+    B, S, cin = src.shape[0], src.shape[1], src.shape[-1]
+    o, cout = S // 2, g.shape[-1]
+    p = torch.zeros(B, S + 2, S + 2, S + 2, cin, dtype=torch.float64, device=DEV)
+    p[:, 1:-1, 1:-1, 1:-1] = src.double()
+    g2 = g.double().reshape(-1, cout)
+    dw = torch.empty(4, 4, 4, cin, cout, dtype=torch.float64, device=DEV)
+    for td in range(4):
+        for th in range(4):
+            for tw in range(4):
+                win = p[:, td:td + 2 * o:2, th:th + 2 * o:2, tw:tw + 2 * o:2].reshape(-1, cin)
+                dw[td, th, tw] = win.t() @ g2
+    return dw
+
+
+def test_weight_gradient_kernels_at_batch_256_against_float64():
+    """The two weight-gradient forms that only see their full split at large batches: the phase-form kernel on the 64 -> 128
+    layer (side 16 -> 8, 131072 reduction rows) and the single-channel layer's 1024-way split (first conv / last transposed conv:
+    float32 grid 32^3, 64 channels of bf16 gradient, 1 M reduction rows) -- against float64 on the same operands."""
+    from voxvae import lib as L
+    L.load()
+    st = ctypes_stream()
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    B = 256
+    src = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=gen).to(torch.bfloat16)
+    g = torch.randn(B, 8, 8, 8, 128, device=DEV, generator=gen).to(torch.bfloat16)
+    ref = _wgrad_ref_gpu_f64(src, g)
+    out = torch.full((4, 4, 4, 64, 128), 7.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(L.load().vv_wgrad_workspace_bytes(B * 8 ** 3, 64 * 64, 128), dtype=torch.uint8, device=DEV)
+    L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), B, 16, 64, 128, L.VV_BF16, L.VV_BF16, L.ptr(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    print('\n[wgrad B=256] phase form 64->128: rel err %.2e' % err)
+    assert err <= 2e-5
+    del src, g, ref
+    src = (torch.rand(B, 32, 32, 32, 1, device=DEV, generator=gen) < 0.2).float()            # an occupancy grid
+    g = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=gen).to(torch.bfloat16)
+    ref = _wgrad_ref_gpu_f64(src, g)
+    out = torch.full((4, 4, 4, 1, 64), 7.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(L.load().vv_wgrad_workspace_bytes(B * 16 ** 3, 64, 64), dtype=torch.uint8, device=DEV)
+    L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), B, 32, 1, 64, L.VV_F32, L.VV_BF16, L.ptr(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    print('[wgrad B=256] single channel, 1024-way split: rel err %.2e' % err)
+    assert err <= 2e-5
+
+
+def ctypes_stream():
+    import ctypes
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

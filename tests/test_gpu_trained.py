@@ -1,0 +1,150 @@
+"""End-to-end parity at a TRAINED operating point.
+
+Every other end-to-end check runs on seeded Glorot weights: a near-random predictor (IoU ~ 0.1, |logit| < 6), where an IoU
+delta is weak evidence and the saturation region of the reference's `clip(sigmoid(l), 1e-7, 1 - 1e-7)` (function.py:79) is
+never reached.  Here the 32^3 VAE is first fitted with the repo's own float32 `fit` (voxvae/trained.py, reference
+nolbo.py:1411-1447) until the CPU oracle itself reports IoU >= 0.5 and |logit| >= 16 on the evaluation batch; the trained
+weights then go to the oracle and to the HIP path in every arithmetic mode:
+
+  f32          logits within 1e-3 of the oracle, occupancy identical outside a 1e-4 band around the threshold (north_star)
+  bf16 / fp8   mean IoU within 1e-3, per-sample IoU within 5e-3
+  BCE          per-sample sums within tolerance although most voxels sit in the saturated region
+  missing_prob = 0.9: the two-pass getEval (nolbo.py:1504-1528) against the composed oracle
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+N_EVAL = 64
+
+
+@pytest.fixture(scope='module')
+def trained():
+    from voxvae import synthetic as syn
+    from voxvae import trained as tr
+    from oracle import c_oracle as co
+    cfg, ep, dp, info = tr.train_operating_point(device=DEV, verbose=True)
+    assert info['reached'], info
+    # evaluation batch: 48 shapes of the training pool + 16 the model has never seen
+    x = np.concatenate([syn.make_voxels(256, 32, seed=4321)[:48], syn.make_voxels(16, 32, seed=777)], axis=0)
+    eps = syn.make_eps(N_EVAL, 64, seed=70)
+    ref = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
+    iou = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
+    print('\n[trained] %d fit steps; oracle IoU %.4f (seen %.4f / unseen %.4f), logits in [%.1f, %.1f], %.1f %% of voxels with |logit| > 15.94'
+          % (info['steps'], iou.mean(), iou[:48].mean(), iou[48:].mean(), ref['logits'].min(), ref['logits'].max(),
+             100.0 * np.mean(np.abs(ref['logits']) > 15.94)))
+    # the operating point the test is about, judged by the ORACLE, not by the path under test
+    assert iou.mean() >= 0.5
+    assert np.abs(ref['logits']).max() >= 16.0
+    return dict(cfg=cfg, ep=ep, dp=dp, x=x, eps=eps, ref=ref, iou=iou, info=info)
+
+
+def _model(t, dtype):
+    import voxvae
+    voxvae.set_default_dtype(dtype)
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=t['cfg'])
+    m._encoder.set_weights_dict(t['ep'])
+    m._decoder.set_weights_dict(t['dp'])
+    return m
+
+
+def _run(m, t):
+    x, eps = torch.from_numpy(t['x']).to(DEV), torch.from_numpy(t['eps']).to(DEV)
+    _, z_act, kl = m._encode_latent(x, eps)
+    probs, logits, stats = m._dec_eng.forward(z_act, x, want_logits=True)
+    # the fused path bench.py times (latent tail, metrics in the last launch) must say the same
+    pred2, stats2, metrics, _ = m.eval_forward_device(x, x, eps)
+    torch.cuda.synchronize()
+    return probs.cpu().numpy(), logits.cpu().numpy(), stats.cpu().numpy().astype(np.float64), stats2.cpu().numpy().astype(np.float64), \
+        kl.cpu().numpy()
+
+
+def test_f32_logits_occupancy_and_saturated_bce_on_trained_weights(trained):
+    t = trained
+    ref = t['ref']
+    probs, logits, stats, stats2, kl = _run(_model(t, 'f32'), t)
+    err = np.abs(logits.astype(np.float64) - ref['logits'])
+    print('\n[trained f32] max |dlogit| %.2e at |logit| up to %.1f; max |dprob| %.2e' % (err.max(), np.abs(ref['logits']).max(),
+                                                                                     np.abs(probs - ref['probs']).max()))
+    assert err.max() <= 1e-3                                                   # north_star: logits within 1e-3 in fp32
+    safe = np.abs(ref['logits']) > 1e-4
+    assert np.array_equal((logits >= 0)[safe], (ref['logits'] >= 0)[safe])    # occupancy exact outside the guard band
+    assert np.array_equal((probs >= 0.5)[safe], (ref['logits'] >= 0)[safe])
+    # counts: exact up to the voxels inside the guard band
+    slack = int((~safe).reshape(N_EVAL, -1).sum(1).max())
+    for col, k in ((1, 'tp'), (2, 'fp'), (3, 'fn')):
+        assert np.abs(stats[:, col] - ref[k]).max() <= slack
+        assert np.abs(stats2[:, col] - ref[k]).max() <= slack
+    # BCE with most voxels saturated: function.py:79's float32 clip (1 - 1e-7 -> 0.99999988) is reproduced, and the per-sample
+    # sum is within 2e-4 (one ulp of p moves log(1 - p) by percents near p -> 1: the formulation is ill-conditioned there and both
+    # sides keep it)
+    sat = np.abs(ref['logits']) > 15.94
+    assert sat.mean() > 0.01, 'the trained net must reach the clip region (%.4f of the voxels do)' % sat.mean()
+    rel = np.abs(stats[:, 0] - ref['bce']) / ref['bce']
+    rel2 = np.abs(stats2[:, 0] - ref['bce']) / ref['bce']
+    print('[trained f32] saturated voxels %.1f %%; per-sample BCE rel err max %.2e (fused path %.2e)' % (100 * sat.mean(), rel.max(), rel2.max()))
+    assert rel.max() <= 2e-4 and rel2.max() <= 2e-4
+    np.testing.assert_allclose(kl, ref['kl'], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8'])
+def test_reduced_precision_iou_on_trained_weights(trained, dtype):
+    t = trained
+    ref = t['ref']
+    probs, logits, stats, stats2, kl = _run(_model(t, dtype), t)
+    for s in (stats, stats2):
+        iou = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
+        d_mean, d_max = abs(iou.mean() - t['iou'].mean()), np.abs(iou - t['iou']).max()
+        assert d_mean <= 1e-3, (dtype, d_mean)                                 # north_star: IoU within 1e-3 of the reference
+        assert d_max <= 5e-3, (dtype, d_max)
+    flips = (logits >= 0) != (ref['logits'] >= 0)
+    print('\n[trained %s] IoU ref %.4f, delta %.2e, max per-sample delta %.2e; %d occupancy flips of %d (largest |ref logit| at a flip %.3f); '
+          'max |dlogit| %.3f' % (dtype, t['iou'].mean(), d_mean, d_max, flips.sum(), flips.size,
+                                 np.abs(ref['logits'][flips]).max() if flips.any() else 0.0,
+                                 np.abs(logits - ref['logits']).max()))
+    # the loss: dominated by the boundary voxels, a few percent at most in reduced precision
+    rel = np.abs(stats[:, 0] - ref['bce']) / ref['bce']
+    assert rel.max() <= (0.05 if dtype == 'bf16' else 0.15), rel.max()
+
+
+def test_two_pass_missing_latents_on_trained_weights(trained):
+    """getEval(missing_prob=0.9) (nolbo.py:1472-1528): masked latent filled with the prototype mean, nearest prototype by the
+    masked distance, prior sample in the masked slots, decoder again -- at the trained operating point the first pass
+    reconstructs badly (most of z is the prototype mean) and the corrected pass differs from it, so both are real tests."""
+    from voxvae import synthetic as syn
+    from oracle import c_oracle as co
+    t = trained
+    n = 16
+    x, eps = t['x'][40:40 + n], t['eps'][40:40 + n]
+    oh, cats = syn.make_onehot(n, 40, seed=6), syn.make_category_vectors(40, 64, seed=12)
+    eps2, mask = syn.make_eps(n, 64, seed=9), syn.make_mask(n, 64, 0.9, seed=14)
+    ref = co.vae_get_eval(t['cfg'], t['ep'], t['dp'], x, x, oh, cats, eps, 0.9, mask, eps2)
+    m = _model(t, 'f32')
+    out = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.9, _eps=eps, _mask=mask, _eps2=eps2)
+    assert len(out) == 10
+    pred, pred_c = np.array(out[0]), np.array(out[5])
+    np.testing.assert_allclose(np.array(m._z_category), ref['z'], atol=2e-5)
+    np.testing.assert_allclose(np.array(m._z_category_corrected), ref['z_c'], atol=2e-5)
+    np.testing.assert_allclose(pred, ref['probs'], atol=2.5e-4)                # |dprob| <= |dlogit| / 4
+    np.testing.assert_allclose(pred_c, ref['probs_c'], atol=2.5e-4)
+    for got, a, b, c in ((out[1:5], '', ref['bce'], ref['acc']), (out[6:10], '_c', ref['bce_c'], ref['acc_c'])):
+        tp, fp, fn = ref['tp' + a].astype(np.float64), ref['fp' + a].astype(np.float64), ref['fn' + a].astype(np.float64)
+        assert abs(float(got[0]) - b.mean()) <= 2e-4 * b.mean()
+        assert abs(float(got[1]) - np.mean(tp / (tp + fp + 1e-10))) < 1e-4
+        assert abs(float(got[2]) - np.mean(tp / (tp + fn + 1e-10))) < 1e-4
+        assert abs(float(got[3]) - c) < 1e-6
+    assert np.abs(ref['logits'] - ref['logits_c']).max() > 1.0                 # the correction changes the reconstruction
+    # bf16: same call, IoU of both passes within the reduced-precision bar
+    mb = _model(t, 'bf16')
+    ob = mb.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.9, _eps=eps, _mask=mask, _eps2=eps2)
+    for p, a in ((np.array(ob[0]), ''), (np.array(ob[5]), '_c')):
+        yh = p.reshape(n, -1) >= 0.5
+        yt = x.reshape(n, -1) > 0.5
+        iou = (yh & yt).sum(1) / np.maximum((yh | yt).sum(1), 1)
+        tp, fp, fn = ref['tp' + a], ref['fp' + a], ref['fn' + a]
+        iou_r = tp / np.maximum(tp + fp + fn, 1)
+        assert abs(iou.mean() - iou_r.mean()) <= 1e-3 and np.abs(iou - iou_r).max() <= 5e-3

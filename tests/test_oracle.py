@@ -193,3 +193,24 @@ def test_c_oracle_under_asan():
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
     p = subprocess.run(['make', '-C', here, '-B', 'asan'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0 and 'asan driver: ok' in p.stdout, p.stdout[-3000:]
+
+
+@pytest.mark.parametrize('name', ['vae_d32_l64_b2', 'vae_d16_l64_b3'])
+def test_c_oracle_two_pass_get_eval_matches_golden(name):
+    """c_oracle.vae_get_eval (fp32 C conv stacks + float32 latent algebra; the checker of the trained-weights parity test)
+    against the float64 definition-level fixtures of the missing-latent path (nolbo.py:1472-1528)."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    D, L, var, B, C = [int(v) for v in g['meta'][:5]]
+    cfg = syn.make_config(D, L, True)
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    x, eps, eps2 = syn.make_voxels(B, D), syn.make_eps(B, L), syn.make_eps(B, L, seed=8)
+    oh, cats, mask = syn.make_onehot(B, C), syn.make_category_vectors(C, L), syn.make_mask(B, L, 0.5)
+    r = co.vae_get_eval(cfg, ep, dp, x, x, oh, cats, eps, 0.5, mask, eps2)
+    np.testing.assert_allclose(r['z'], g['p5_z'], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(r['z_c'], g['p5_z_corr'], rtol=0, atol=5e-6)
+    assert np.array_equal(r['argmin_masked'], g['p5_argmin_masked'].astype(np.int64))
+    np.testing.assert_allclose(r['logits'], g['p5_logits'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r['logits_c'], g['p5_logits_c'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r['bce'], g['p5_bce'], rtol=2e-6)
+    np.testing.assert_allclose(r['bce_c'], g['p5_bce_c'], rtol=2e-6)
+    assert abs(r['acc'] - g['p5_scalars'][3]) < 1e-12 and abs(r['acc_c'] - g['p5_scalars'][7]) < 1e-12
