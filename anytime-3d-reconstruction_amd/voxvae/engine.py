@@ -79,6 +79,11 @@ def quant_fp8(w, cout_axis):
     return (w / s.view(shape)).contiguous(), s.contiguous()
 
 
+def fp8_layers_off():
+    """Layers kept on bf16 operands in 'fp8' mode: VV_FP8_OFF=E5,D2 (names as in bench.py's layer table)."""
+    return set(n for n in os.environ.get('VV_FP8_OFF', '').replace(' ', '').split(',') if n)
+
+
 class _EngineBase:
     def __init__(self, structure, dtype, device):
         _require_gpu()
@@ -91,6 +96,8 @@ class _EngineBase:
         self.fp8 = self.dt == L.VV_FP8
         if self.fp8:
             self.dt = L.VV_BF16
+            from . import fp8_policy
+            self.fp8_policy = fp8_policy()        # 'wide': only the layers with a direct fp8 kernel; 'all': every eligible layer
         self.tdt = _tdtype(self.dt)
         self.device = torch.device(device)
         self.params = {}          # name -> float32 CUDA tensor, Keras layout (the trainable/master copy)
@@ -202,7 +209,10 @@ class EncoderEngine(_EngineBase):
         L.call('vv_pack_conv_k4', L.ptr(p['conv0/kernel']), L.ptr(self.packed['w0']), 1, f[0], self.dt, st)
         for i in range(1, len(f) - 1):
             # Cin 64 (the second layer) has an fp8 form too (tap-pair rows); VV_FP8_E2=0 keeps it on the bf16 direct kernel
-            q = self.fp8 and (f[i - 1] % 128 == 0 or (f[i - 1] == 64 and os.environ.get('VV_FP8_E2', '1') != '0'))
+            q = self.fp8 and (f[i - 1] % 128 == 0 or (f[i - 1] == 64 and os.environ.get('VV_FP8_E2', '1') != '0')) \
+                and ('E%d' % (i + 1)) not in fp8_layers_off()
+            if q and self.fp8_policy == 'wide':
+                q = bool(L.load().vv_conv3d_k4s2_direct_fp8_supported(self.D >> i, f[i - 1], f[i])) and os.environ.get('VV_FP8_E2', '1') != 'igemm'
             wk = p['conv%d/kernel' % i]
             if q:
                 wk, qs = self._quant_fp8(wk, 4)
@@ -224,7 +234,7 @@ class EncoderEngine(_EngineBase):
                 L.call('vv_pack_conv_k4_skip', L.ptr(p['conv%d/kernel' % i]), L.ptr(ws), f[i - 1], f[i], st)
                 self.packed['ws%d' % i] = ws
         i = len(f) - 1
-        q = self.fp8 and (self.S ** 3 * f[i - 1]) % 128 == 0
+        q = self.fp8 and self.fp8_policy == 'all' and (self.S ** 3 * f[i - 1]) % 128 == 0 and ('E%d' % (i + 1)) not in fp8_layers_off()
         wk = p['conv%d/kernel' % i]
         if q:
             wk, qs = self._quant_fp8(wk, 4)
@@ -355,9 +365,11 @@ class DecoderEngine(_EngineBase):
         for i in range(1, len(f) - 1):
             side_i = self.S << (i - 1)
             direct = not os.environ.get('VV_NO_DIRECT') and bool(L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt))
-            q = self.fp8 and f[i - 1] % 128 == 0
+            q = self.fp8 and f[i - 1] % 128 == 0 and ('D%d' % (i + 1)) not in fp8_layers_off()
             mode = os.environ.get('VV_FP8_LAST', 'direct')
             direct8 = q and direct and mode not in ('0', 'igemm') and bool(L.load().vv_convT3d_k4s2_direct_fp8_supported(side_i, f[i - 1], f[i]))
+            if q and self.fp8_policy == 'wide' and not direct8:
+                q = False
             if q and direct and mode == '0':
                 q = False
             wk = p['convT%d/kernel' % i]

@@ -5,7 +5,7 @@ IoU delta or an occupancy flip count measured there says little (flips cancel, a
 reference's `clip(sigmoid(l), 1e-7, 1 - 1e-7)` saturates is never reached end to end).  No trained weights exist in
 the reference, so this module makes some: the 32^3 VAE fitted for a few hundred float32 steps
 on a fixed pool of the seeded synthetic shapes until it reconstructs them (IoU >= `min_iou`) and emits logits
-beyond the clip (max |logit| >= `min_abs_logit`), checked on the GPU in evaluation mode (moving statistics).
+beyond the clip (max |logit| >= `min_abs_logit`, at least `min_saturated` of the voxels past +-15.94), checked on the GPU in evaluation mode (moving statistics).
 
     cfg, enc_p, dec_p, info = train_operating_point()      # ~10 s on one MI355X
 
@@ -23,7 +23,7 @@ from . import synthetic as syn
 
 
 def train_operating_point(voxel=32, latent=64, batch=64, pool=256, lr=1e-3, seed=0, min_iou=0.6, min_abs_logit=17.0,
-                          check_every=100, max_steps=2000, device='cuda:0', dtype='f32', verbose=False):
+                          min_saturated=0.01, check_every=100, max_steps=3000, device='cuda:0', dtype='f32', verbose=False):
     """-> (config, encoder params, decoder params, info).  Trains with `dtype` arithmetic ('f32' = the reference's)."""
     import voxvae
     import src.module.nolbo as nolbo
@@ -53,13 +53,15 @@ def train_operating_point(voxel=32, latent=64, batch=64, pool=256, lr=1e-3, seed
             s = stats.double()
             iou = float((s[:, 1] / torch.clamp(s[:, 1] + s[:, 2] + s[:, 3], min=1.0)).mean())
             amax = float(logits.abs().max())
-            hist.append((step, iou, amax))
+            sat = float((logits.abs() > 15.94).float().mean())      # beyond the reference's clip(p, 1e-7, 1 - 1e-7)
+            hist.append((step, iou, amax, sat))
             if verbose:
-                print('trained operating point: step %d  IoU %.3f  max|logit| %.1f' % (step, iou, amax), file=sys.stderr)
-            ok = iou >= min_iou and amax >= min_abs_logit
+                print('trained operating point: step %d  IoU %.3f  max|logit| %.1f  saturated %.2f %%' % (step, iou, amax, 100 * sat), file=sys.stderr)
+            ok = iou >= min_iou and amax >= min_abs_logit and sat >= min_saturated
         ep, dp = model._encoder.get_weights_dict(), model._decoder.get_weights_dict()
         info = {'steps': step, 'batch': batch, 'pool': pool, 'lr': lr, 'fit_dtype': dtype, 'history': hist, 'reached': ok,
-                'iou_eval_mode_gpu': hist[-1][1], 'max_abs_logit_gpu': hist[-1][2]}
+                'iou_eval_mode_gpu': hist[-1][1], 'max_abs_logit_gpu': hist[-1][2],
+                'saturated_fraction_gpu': hist[-1][3]}
         del model
         return cfg, ep, dp, info
     finally:

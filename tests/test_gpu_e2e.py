@@ -101,15 +101,18 @@ def test_f32_batch_invariance_and_c_oracle():
     np.testing.assert_allclose(big['stats'][12:, 0], c['bce'], rtol=1e-4)
 
 
-@pytest.mark.parametrize('dtname,B', [('f32', 8), ('bf16', 8), ('fp8', 8), ('fp8+d5', 8)])
+@pytest.mark.parametrize('dtname,B', [('f32', 8), ('bf16', 8), ('fp8', 8), ('fp8/all', 8), ('fp8/all+d5', 8)])
 def test_d64_vae_config_against_c_oracle(dtname, B, monkeypatch):
     """BASELINE configs 3/5 shape (the reference's native 64^3 grid, test_modelnet_VAE.py:174-189): D=64, L=64.  'fp8' is
     config 5's arithmetic: E3-E5 / D2-D3 on e4m3fn operands, gated on the IoU delta like bf16."""
     from oracle import c_oracle as co
     from voxvae import synthetic as syn
-    if dtname == 'fp8+d5':                      # opt-in: e4m3fn hand-over into the last layer as well (DESIGN.md section 7)
+    import voxvae
+    if dtname.startswith('fp8/all'):            # every eligible layer on fp8 operands (default policy 'wide': the direct-kernel layers)
+        monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
+    if dtname.endswith('+d5'):                  # opt-in: e4m3fn hand-over into the last layer as well (DESIGN.md section 7)
         monkeypatch.setenv('VV_FP8_D5', '1')
-        dtname = 'fp8'
+    dtname = dtname.split('/')[0].split('+')[0]
     cfg = syn.make_config(64, 64, True)
     ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
     x = syn.make_voxels(B, 64, seed=64)

@@ -303,8 +303,8 @@ def test_eval_after_training_mode_forward_uses_the_moved_statistics():
     want = co.vae_eval_forward(cfg, moved_e, moved_d, x, x, eps)['probs']
     p1, _, _, _ = model.eval_forward_device(xd, xd, epsd)
     p1 = p1.cpu().numpy()
-    assert np.abs(want - p0).max() > 1e-3                                      # the statistics moved enough to matter
-    np.testing.assert_allclose(p1, want, atol=2.5e-4)
+    assert np.abs(want - p0).max() > 2e-4                                      # one momentum-0.99 update moves the predictions by this much ...
+    np.testing.assert_allclose(p1, want, atol=3e-5)                            # ... and the float32 path follows it an order of magnitude closer
     # decoder-only training-mode pass (the corrected pass of getEval) marks the decoder's fold stale too
     model._train_helper().decoder_training_mode(torch.from_numpy(eps).to(DEV), xd)
     assert not model._dec_eng._folded and model._enc_eng._folded
@@ -487,7 +487,7 @@ def test_fit_at_batch_256_replication_and_permutation(dtype):
     assert max(worst.values()) <= gate, {k: v for k, v in worst.items() if v > gate}
     # per-sample losses / counts repeat with period 16, moving statistics agree
     srel = (st256.view(16, 16, 4) - st16[None]).abs().max() / st16.abs().max()
-    assert float(srel) <= (1e-5 if dtype == 'f32' else 2e-2)
+    assert float(srel) <= (2e-4 if dtype == 'f32' else 2e-2)     # per-sample BCE sums: batch statistics summed in another order
     assert float((kl256.view(16, 16) - kl16[None]).abs().max()) <= 1e-3 * float(kl16.abs().max())
     for k in mov16:
         assert _rel_max(mov256[k], mov16[k]) <= (1e-5 if dtype == 'f32' else 1e-3), k
@@ -499,7 +499,8 @@ def test_fit_at_batch_256_replication_and_permutation(dtype):
     worst = {n: _rel_max(gb[n], ga[n]) for n in ga if n != 'dec/dense/bias'}
     print('[fit B=256 %s] permutation: worst gradient rel err %.2e (%s)' % (dtype, max(worst.values()), max(worst, key=worst.get)))
     assert max(worst.values()) <= gate, {k: v for k, v in worst.items() if v > gate}
-    assert float((stb - sta[torch.from_numpy(perm).to(DEV)]).abs().max() / sta.abs().max()) <= (1e-5 if dtype == 'f32' else 2e-2)
+    # per-sample (bce, TP, FP, FN): a voxel whose logit is ~0 may land on the other side in another summation order (one count = 6e-5 here)
+    assert float((stb - sta[torch.from_numpy(perm).to(DEV)]).abs().max() / sta.abs().max()) <= (2e-4 if dtype == 'f32' else 2e-2)
 
 
 def _wgrad_ref_gpu_f64(src, g):
