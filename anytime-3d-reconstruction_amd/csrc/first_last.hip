@@ -258,17 +258,23 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
 // only), P is published once per cell, and the four BCE / TP / FP / FN sums stay in registers for the whole sweep.
 // The voxel math uses the hardware exp / log / rcp (relative error ~1e-7, far below the bf16 operand rounding) and
 // thresholds on the logit (sigmoid(l) >= 0.5 <=> l >= 0, function.py:110).
-constexpr int SW_ROWS = 100, SW_XB = 13 * 1024, SW_NX = 2, SW_PP = 36, SW_PSZ = 100 * SW_PP;   // X slot bytes (104 rows); P row pitch / buffer floats
-constexpr int SW_LDS = SW_NX * SW_XB + 1024 + 24 * 128 + 3 * SW_PSZ * 4;
+// P rows are dense (32 taps = 8 quads of 16 B); quad q of the row of halo cell (zh, zw) sits at slot q ^ (zw & 7): the gather reads
+// whole quads with ds_read_b128 and this slot key makes every one of its lane groups conflict-free (exhaustive search over
+// a*zh + b*zw keys and pitches 32 / 36 / 40: profiles/microbench/d5_swz.py; the dword gathers of rounds 1-2 at pitch 36 were 4-way).
+constexpr int SW_ROWS = 100, SW_XB = 13 * 1024, SW_NX = 2, SW_PP = 32, SW_PSZ = 100 * SW_PP;   // X slot bytes (104 rows); P row pitch / buffer floats
+// LDS: 2 plane slots + 1 KiB sink + PL + PH = 53,248 B (+ 64 B of static sums): THREE workgroups per CU (rounds 1-2: 73.6 KB, two).
+// The 4th MFMA row tile reads 24 rows past a plane slot (into the next slot / the sink and the head of PL): whatever it finds only
+// reaches accumulator rows >= 104, which are never published.
+constexpr int SW_LDS = SW_NX * SW_XB + 1024 + 2 * SW_PSZ * 4;
 
-__global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256, 3) void final_bce_sweep_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                                  const float *__restrict__ target, float *__restrict__ probs,
                                                                  float *__restrict__ logits, float *__restrict__ partials,
                                                                  int din_log2, unsigned x_bytes, float gamma, float epsilon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Xs = smem;                                             // ring of SW_NX planes x [104 rows][128 B], slot-swizzled; 1 KiB sink; 24 spare rows
-    float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024 + 24 * 128);   // P_d[td 0,1]      [100][36]
-    float *PH = PL + SW_PSZ;                                     // P_d / P_{d-1}[td 2,3]  [2][100][33]
+    char *Xs = smem;                                             // ring of SW_NX planes x [104 rows][128 B], slot-swizzled; 1 KiB sink
+    float *PL = reinterpret_cast<float *>(smem + SW_NX * SW_XB + 1024);   // P_d[td 0,1]  [100][32]
+    float *PH = PL + SW_PSZ;                                     // P_d[td 2,3]  [100][32]: read in step d for the outputs of step d+1
     __shared__ float red[4][4];
     const int li = din_log2, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
     const int T = gridDim.x;
@@ -323,7 +329,6 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         for (int e = 0; e < 4; ++e) { o[e] = static_cast<__bf16>(w0v[e]); o[4 + e] = static_cast<__bf16>(w1v[e]); }
         fb[ks] = *reinterpret_cast<const uint4 *>(&o);
     }
-    for (int i = tid; i < SW_PSZ; i += 256) PH[i] = 0.f;         // P_{-1} = 0
 
     // gather role: s = od parity slot, ohh = output row inside the tile, mw = cell column (both pw per lane)
     const int mw = tid & 7, ohh = (tid >> 3) & 15, sl = tid >> 7;
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     const int oh = 2 * h0 + ohh, ow = 2 * (w0 + mw);
     const float hi = 1.0f - epsilon;
     float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    float lo0 = 0.f, lo1 = 0.f;                                  // td in {2,3} contributions of P_{d-1} to this step's outputs (P_{-1} = 0)
 
     // P_d = X_d W^T for this wave's two row tiles and its tap half: D[tap][cell], weights-first
     auto mfma_plane = [&](int sp, f32x16 (&acc)[2]) {             // sp = ring slot of the plane
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     // Software pipeline: step d publishes P_d (computed during step d-1) and then runs the MFMAs of plane d+1 in the same
     // instruction stream as the gather / loss math of plane d (matrix pipe under the VALU and LDS work).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // plane 0
-    __syncthreads();                                             // ... and the zeroed P_{-1}, for every wave
+    __syncthreads();                                             // ... for every wave
     f32x16 acc[2];
     mfma_plane(0, acc);
     stage(1, 1);
@@ -371,14 +377,15 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
     for (int d = 0; d <= n; ++d) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
         // of one (td, th): one 16-byte store per quad
-        float *Pw = nt == 0 ? PL : PH + (oldh ^ 1) * SW_PSZ;
+        float *Pw = nt == 0 ? PL : PH;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = (mt0 + 2 * j) * 32 + fr;
             if (row < SW_ROWS) {
+                const int zwk = (row - (row / 10) * 10) & 7;              // slot key of this halo cell
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4 *>(Pw + row * SW_PP + 8 * g + 4 * fh) =
+                    *reinterpret_cast<f32x4 *>(Pw + row * SW_PP + (((2 * g + fh) ^ zwk) << 2)) =
                         f32x4{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
             }
         }
@@ -390,8 +397,14 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
         //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
         // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
-        // (Fetching the pair a step ahead -- into registers by a second asm load, or into LDS by DMA -- is a measured dead
-        // end, DESIGN.md section 4d: the compiler copies / re-uses the registers of a load it believes complete.)
+        // An asm output is a READY value to the compiler: nothing in the language stops it from copying y or re-using its
+        // registers while the load is in flight.  tests/test_isa_lint.py checks on the generated code that no instruction
+        // names the pair between this load and the counted wait below that lands it ("+v"(y)); round 2's dead ends came from
+        // exactly that (a look-ahead load whose last instance was DEAD: its registers went to the logit accumulators of the
+        // last plane while it was in flight -- DESIGN.md section 4d).  The two compiler-managed alternatives were built in round 3
+        // and are worse: a plain load of the noalias argument is moved by the compiler across the asm statements into the
+        // `ovalid` branch (behind the counted wait, whose count then no longer holds: wrong logits), a volatile load becomes a
+        // system-scope flat load with an immediate vmcnt(0).
         float2 y;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
         stage(d + 2, oldh);
@@ -401,15 +414,25 @@ __global__ __launch_bounds__(256, 2) void final_bce_sweep_kernel(const __bf16 *_
         f32x16 acc_next[2];
         mfma_plane(oldh ^ 1, acc_next);
 
-        float l0 = 0.f, l1 = 0.f;
-        const float *Pold = PH + oldh * SW_PSZ;
+        // gather: per ah the tap quads (tw 0..3) of the three cells mw, mw+1, mw+2 -- ds_read_b128, conflict-free.  The td in {0,1}
+        // half of P_d (PL) completes the output planes od = 2d - 1 + sl together with the td in {2,3} half of P_{d-1}, which was
+        // gathered a step ago into (lo0, lo1): PH is read in the step that publishes it, so ONE buffer holds it.
+        float l0 = lo0, l1 = lo1;
+        lo0 = 0.f; lo1 = 0.f;
 #pragma unroll
         for (int ah = 0; ah < 2; ++ah) {
             const int zh = mh + ph - ah + 1, th = 1 - ph + 2 * ah;
-            const int off = (zh * 10 + mw) * SW_PP + (sl * 4 + th) * 4;
-            const float *r0 = PL + off, *r1 = Pold + off;
-            l0 += r0[SW_PP + 1] + r0[3] + r1[SW_PP + 1] + r1[3];                         // pw = 0
-            l1 += r0[2 * SW_PP] + r0[SW_PP + 2] + r1[2 * SW_PP] + r1[SW_PP + 2];   // pw = 1
+            const int q = sl * 4 + th, rowb = (zh * 10 + mw) * SW_PP;
+            const int o0 = rowb + ((q ^ (mw & 7)) << 2), o1 = rowb + SW_PP + ((q ^ ((mw + 1) & 7)) << 2),
+                      o2 = rowb + 2 * SW_PP + ((q ^ ((mw + 2) & 7)) << 2);
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(PL + o0), a1 = *reinterpret_cast<const f32x4 *>(PL + o1),
+                        a2 = *reinterpret_cast<const f32x4 *>(PL + o2);
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(PH + o0), b1 = *reinterpret_cast<const f32x4 *>(PH + o1),
+                        b2 = *reinterpret_cast<const f32x4 *>(PH + o2);
+            l0 += a1[1] + a0[3];                                         // pw = 0: cell mw+1 (tw 1), cell mw (tw 3)
+            l1 += a2[0] + a1[2];                                         // pw = 1: cell mw+2 (tw 0), cell mw+1 (tw 2)
+            lo0 += b1[1] + b0[3];
+            lo1 += b2[0] + b1[2];
         }
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
         if (ovalid) {
