@@ -135,6 +135,10 @@ class _ModelnetBase(object):
         if len(inputs) == 2 or category_vectors is None:
             return self._getEval_legacy(inputs, missing_prob, _eps, _mask)
         input_images, output_images, category_list = inputs
+        if missing_prob == 0.0 and isinstance(input_images, np.ndarray) and isinstance(output_images, np.ndarray):
+            out = self._getEval_host_chunked(input_images, output_images, category_list, category_vectors, _eps)
+            if out is not None:
+                return out
         x, y = self._dev_pair(input_images, output_images)
         onehot = self._dev(category_list)
         cats = self._dev(category_vectors)
@@ -170,6 +174,63 @@ class _ModelnetBase(object):
         pred_c, _, mc = self._decode_metrics(zc_act, y)                           # :1520-1527
         self._z_category_corrected = DeviceArray(zc)
         return res + (DeviceArray(pred_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
+
+    def _getEval_host_chunked(self, input_images, output_images, category_list, category_vectors, _eps):
+        """getEval(missing_prob=0) on HOST arrays (the reference's calling convention, test_modelnet_VAE.py:114-130) as a
+        pipeline over sample ranges: the upload of chunk k+1 runs under the kernels of chunk k, the download of chunk k's
+        prediction (into a recycled pinned block) under the kernels of chunk k+1 -- two streams, this model's one pair of
+        engines (per-stream workspaces).  Every kernel of the path treats samples independently with a batch-size-independent
+        summation order, so the result is the whole-batch result bit for bit (tests/test_gpu_api.py).  Returns None when the
+        batch is too small to split or no pinned block is available (the caller then takes the plain path)."""
+        from voxvae import hostio as _H
+        B = int(input_images.shape[0])
+        nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2'))
+        if nchunk < 2 or B < 64 * nchunk or input_images.dtype != np.float32 or not input_images.flags['C_CONTIGUOUS']:
+            return None
+        same = output_images is input_images
+        if not same and (output_images.dtype != np.float32 or not output_images.flags['C_CONTIGUOUS'] or output_images.shape != input_images.shape):
+            return None
+        pd = _H.prediction_host_dtype()
+        host, hview = _H.pinned_array(tuple(input_images.shape), pd)
+        if host is None:
+            return None
+        dev = self._device
+        main = torch.cuda.current_stream(dev)
+        if getattr(self, '_io_streams', None) is None or len(self._io_streams) != nchunk:
+            self._io_streams = [torch.cuda.Stream(device=dev) for _ in range(nchunk)]
+        Lz = self._latent_dim
+        eps = None
+        if self._variational:
+            eps = torch.randn(B, Lz, dtype=torch.float32, device=dev) if _eps is None else self._dev(_eps)
+        onehot, cats = self._dev(category_list), self._dev(category_vectors)
+        self._enc_eng.ensure_packed()               # weight packing (first call / after a weight change) stays on the caller's stream
+        self._dec_eng.ensure_packed()
+        bounds = [B * k // nchunk // 4 * 4 for k in range(nchunk)] + [B]
+        zs, stats, preds = [], [], []
+        for k, s in enumerate(self._io_streams):
+            lo, hi = bounds[k], bounds[k + 1]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                # pageable source, synchronous copy at the PCIe rate.  (Staging the chunk through a pinned block to make the upload
+                # asynchronous was measured and is NOT used: an async host -> device copy issued beside running kernels took 10-50x
+                # longer on this platform -- profiles/microbench/mb_pin.py: 78 ms against 14 ms for two matmuls with and without it.)
+                x = torch.from_numpy(input_images[lo:hi]).to(dev)
+                y = x if same else torch.from_numpy(output_images[lo:hi]).to(dev)
+                z, z_act, _, h1 = self._encode_decode_seed(x, None if eps is None else eps[lo:hi])
+                pred, _, st_ = self._dec_eng.forward(z_act, y, h1=h1)
+                hview[lo:hi].copy_(_H.device_prediction_as(pred), non_blocking=True)
+            for t in (z, st_, pred):
+                t.record_stream(main)
+            zs.append(z); stats.append(st_); preds.append(pred)
+        for s in self._io_streams:
+            main.wait_stream(s)
+        z = torch.cat(zs, dim=0)
+        m = _E.shape_metrics(torch.cat(stats, dim=0))
+        _, acc = self._category_acc(z, cats, onehot)
+        self._z_category = DeviceArray(z)
+        for s in self._io_streams:                  # the host array is handed out: its downloads must have landed
+            s.synchronize()
+        return (_H.HostPrediction(host, preds), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]), 0, 0, 0, 0, 0)
 
     def _train_helper(self):
         from voxvae import train as _T

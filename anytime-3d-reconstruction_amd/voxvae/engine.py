@@ -55,17 +55,21 @@ class LayerTimer:
 
 
 class _Workspace:
-    """Grow-only scratch buffer shared by the layers of one engine (split-K slabs, loss partials)."""
+    """Grow-only scratch buffers shared by the layers of one engine (split-K slabs, loss partials), ONE PER HIP STREAM: the
+    same engine can then run independent batches on several streams at once (the chunked host-array path of getEval,
+    voxvae/hostio.py) without a second in-flight step overwriting the first one's slabs."""
 
     def __init__(self, device):
         self.device = device
-        self.buf = None
+        self.bufs = {}
 
     def get(self, nbytes):
         nbytes = max(int(nbytes), 16)
-        if self.buf is None or self.buf.numel() < nbytes:
-            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self.buf
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return buf
 
 
 def quant_fp8(w, cout_axis):
@@ -216,8 +220,14 @@ class EncoderEngine(_EngineBase):
             wk = p['conv%d/kernel' % i]
             if q:
                 wk, qs = self._quant_fp8(wk, 4)
-            w = self._empty(f[i], 64 * f[i - 1], dtype=torch.uint8 if q else None)
-            L.call('vv_pack_conv_k4', L.ptr(wk), L.ptr(w), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
+            small = (not q and not os.environ.get('VV_NO_SKIP')
+                     and bool(L.load().vv_conv3d_k4s2_skip_supported(self.D >> i, f[i - 1], f[i], self.dt)
+                              or L.load().vv_conv3d_k4s2_pos_supported(self.D >> i, f[i - 1], f[i], self.dt)))
+            if small and not self._want_fold:
+                w = None        # the training step packs the skip / position image of this layer per use (voxvae/train.py: _conv)
+            else:
+                w = self._empty(f[i], 64 * f[i - 1], dtype=torch.uint8 if q else None)
+                L.call('vv_pack_conv_k4', L.ptr(wk), L.ptr(w), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
             self.packed['w%d' % i] = w
             self.packed['scale%d' % i], self.packed['shift%d' % i] = self._fold('bn%d' % i, f[i])
             if q:
@@ -378,6 +388,10 @@ class DecoderEngine(_EngineBase):
             if direct8:
                 pk['wq8f%d' % i] = self._empty(64 * f[i - 1] * f[i], dtype=torch.uint8)
                 L.call('vv_pack_convT_k4s2_frag_fp8', L.ptr(wk), L.ptr(pk['wq8f%d' % i]), f[i - 1], f[i], st)
+            elif (not q and not self._want_fold and not os.environ.get('VV_NO_SKIP')
+                  and (L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)
+                       or L.load().vv_convT3d_k4s2_pos_supported(side_i, f[i - 1], f[i], self.dt))):
+                pk['w%d' % i] = None    # training step: the skip / position image is packed per use (voxvae/train.py: _convT)
             else:
                 pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1], dtype=torch.uint8 if q else None)
                 L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(pk['w%d' % i]), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)

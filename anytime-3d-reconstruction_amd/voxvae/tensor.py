@@ -25,10 +25,11 @@ class DeviceArray(object):
         return self.t
 
     def numpy(self):
+        from . import hostio
         t = self.t
-        if t.dtype == torch.bfloat16:
-            t = t.float()
-        return t.detach().cpu().numpy()
+        if t.is_cuda and t.dim() == 5 and t.dtype == torch.float32 and hostio.prediction_host_dtype() != 'float32':
+            t = hostio.device_prediction_as(t)          # opt-in: probabilities cross PCIe as float16 / uint8 occupancy
+        return hostio.to_host(t)                        # large tensors: recycled pinned block, no pageable staging
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()

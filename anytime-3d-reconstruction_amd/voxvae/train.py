@@ -266,10 +266,22 @@ class Trainer:
         the engine's image of the same weights) and the data gradients of the transposed layers (packed here)."""
         dt, st = self.dt, _st()
         wp = packed
+        y = self._aempty(B, side // 2, side // 2, side // 2, cout)
+        lib = L.load()
+        if not os.environ.get('VV_NO_SKIP') and (lib.vv_conv3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_conv3d_k4s2_pos_supported(side, cin, cout, dt)):
+            # 8^3 -> 4^3 / 4^3 -> 2^3 (bf16): the whole-samples-in-LDS and position-major kernels of the evaluation path, raw output
+            # (no scale / shift / activation: BatchNorm follows with batch statistics); their weight image is packed per use
+            wsk = self._aempty(64 * cin * cout)
+            L.call('vv_pack_conv_k4_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
+            if side == 4:
+                ws = self.ws.get(lib.vv_conv3d_k4s2_pos_workspace_bytes(B, cin, cout))
+                L.call('vv_conv3d_k4s2_pos_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
+            else:
+                L.call('vv_conv3d_k4s2_skip_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
+            return y
         if wp is None:
             wp = self._aempty(cout, 64 * cin)
             L.call('vv_pack_conv_k4', L.ptr(w_keras), L.ptr(wp), cin, cout, dt, st)
-        y = self._aempty(B, side // 2, side // 2, side // 2, cout)
         if L.load().vv_conv3d_k4s2_direct_supported(side, cin, cout, dt):
             L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
         else:
@@ -282,6 +294,16 @@ class Trainer:
         transposed layers (packed / packed_frag = the engine's images) and the data gradients of the strided convolutions."""
         dt, st = self.dt, _st()
         y = self._aempty(B, 2 * side, 2 * side, 2 * side, cout)
+        lib = L.load()
+        if not os.environ.get('VV_NO_SKIP') and (lib.vv_convT3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_convT3d_k4s2_pos_supported(side, cin, cout, dt)):
+            wsk = self._aempty(64 * cin * cout)              # 4^3 -> 8^3 / 2^3 -> 4^3 (bf16): see _conv
+            L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
+            if side == 2:
+                ws = self.ws.get(lib.vv_convT3d_k4s2_pos_workspace_bytes(B, cin, cout))
+                L.call('vv_convT3d_k4s2_pos_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
+            else:
+                L.call('vv_convT3d_k4s2_skip_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
+            return y
         if (L.load().vv_convT3d_k4s2_whole_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT')
                 and not os.environ.get('VV_NO_WHOLE')):
             # 8^3 x 128 -> 16^3 x 64 (the widest decoder layer forward, and the data gradient of the widest encoder layer):
@@ -308,7 +330,7 @@ class Trainer:
     def step(self, x, y, eps=None, drop_mask=None, drop_scale=1.0):
         """x, y: float32 CUDA [B,D,D,D,1].  Returns device tensors (loss_kl or None, stats [B,4], metrics [4])."""
         self.enc.ensure_packed(fold=False)
-        self.dec.ensure_packed(fold=False)
+        self.dec.ensure_packed(fold=False)      # (packing the decoder on a side stream under the encoder's forward was measured: +0.11 ms per step)
         self.grads.begin_step()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)

@@ -598,3 +598,73 @@ def test_eval_step_as_hip_graph_is_identical():
         out = g(x, None, e)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
+    """getEval on HOST arrays (the reference's calling convention, test_modelnet_VAE.py:114-130) runs as a two-chunk pipeline on
+    two streams with the prediction downloaded into a recycled pinned block (voxvae/hostio.py).  Must hold: the same bits as
+    the one-batch device path for the prediction and the per-sample latent, the same scalars, block recycling when the caller
+    drops its result, and the opt-in float16 / uint8 return types."""
+    import gc
+    import voxvae
+    from voxvae import hostio
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('bf16')
+    voxvae.set_default_device('cuda:0')
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(32, 64, True)
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(syn.make_encoder_params(cfg['encoder']))
+    m._decoder.set_weights_dict(syn.make_decoder_params(cfg['decoder']))
+    B = 160                                                      # two chunks of 80
+    x, eps = syn.make_voxels(B, 32, seed=21), syn.make_eps(B, 64, seed=22)
+    oh, cats = syn.make_onehot(B, 40), syn.make_category_vectors(40, 64)
+    xd = torch.from_numpy(x).to('cuda:0')
+    ref = m.getEval(inputs=(xd, xd, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)          # device tensors: one batch, one stream
+    ref_pred, ref_z = np.array(ref[0]), np.array(m._z_category)
+    out = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)            # host arrays: the pipeline
+    assert isinstance(out[0], hostio.HostPrediction) and out[5:] == (0, 0, 0, 0, 0)
+    pred = np.array(out[0])
+    assert pred.dtype == np.float32 and pred.shape == x.shape
+    np.testing.assert_array_equal(pred, ref_pred)
+    np.testing.assert_array_equal(np.array(m._z_category), ref_z)
+    np.testing.assert_allclose([float(v) for v in out[1:5]], [float(v) for v in ref[1:5]], rtol=1e-6)
+    assert torch.equal(out[0].torch(), ref[0].torch())
+    # a target array different from the input, and a batch too small to split (plain path)
+    y = syn.make_voxels(B, 32, seed=23)
+    o2 = m.getEval(inputs=(x, y, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    r2 = m.getEval(inputs=(xd, torch.from_numpy(y).to('cuda:0'), oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    np.testing.assert_array_equal(np.array(o2[0]), np.array(r2[0]))
+    np.testing.assert_allclose(float(o2[1]), float(r2[1]), rtol=1e-6)
+    small = m.getEval(inputs=(x[:8], x[:8], oh[:8]), category_vectors=cats, missing_prob=0.0, _eps=eps[:8])
+    assert not isinstance(small[0], hostio.HostPrediction)
+    # recycling: dropping the results returns their pinned blocks; the next call takes one from the pool instead of pinning anew
+    del out, pred, o2, small
+    gc.collect()
+    free_before = sum(len(v) for v in hostio._POOL.values())
+    held = hostio._OUT['n']                                      # ref_pred (np.array of a DeviceArray) lives in a pinned block too
+    assert free_before >= 1 and held == 1
+    o3 = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    assert sum(len(v) for v in hostio._POOL.values()) == free_before - 1 and hostio._OUT['n'] == held + 1
+    view = np.array(o3[0])[3]                                    # a view keeps the block out of the pool ...
+    del o3
+    gc.collect()
+    assert hostio._OUT['n'] == held + 1
+    np.testing.assert_array_equal(view, ref_pred[3])
+    del view
+    gc.collect()
+    assert hostio._OUT['n'] == held                              # ... and its death returns it
+    # opt-in return types
+    try:
+        hostio.set_prediction_host_dtype('uint8')
+        o8 = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+        p8 = np.array(o8[0])
+        assert p8.dtype == np.uint8
+        np.testing.assert_array_equal(p8, (ref_pred >= 0.5).astype(np.uint8))
+        np.testing.assert_array_equal(np.array(m.getEval(inputs=(xd, xd, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)[0]), p8)   # DeviceArray path too
+        hostio.set_prediction_host_dtype('float16')
+        p16 = np.array(m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)[0])
+        assert p16.dtype == np.float16
+        np.testing.assert_array_equal(p16, ref_pred.astype(np.float16))
+    finally:
+        hostio.set_prediction_host_dtype('float32')
