@@ -59,7 +59,7 @@ __device__ __forceinline__ void cw_wait_vm() {
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
-                                                     __bf16 *__restrict__ y, int npar, int dbg) {
+                                                     __bf16 *__restrict__ y, int npar) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
             CW_MFMA4(P);
             CW_WAIT(Q, 0);                           // every LDS read of this chunk has returned: its stage may be refilled
             // The next chunk's piece has landed.  Issued after it: one more piece, and, in the two chunks that follow a
-            // parity's epilogue, that epilogue's 8 stores (between the pieces in the in-order counter).
+            // parity's epilogue, that epilogue's 8 stores (between the pieces in the in-order counter).  The count is only right
+            // while the epilogue issues AT LEAST 8 vector-memory instructions (fewer = this wait no longer covers the piece);
+            // tests/test_isa_lint.py pins, on the generated code, how many waits a piece survives before one covers it.
             if (J < 2 && pi > 0) cw_wait_vm<9>();
             else cw_wait_vm<1>();
             __builtin_amdgcn_s_barrier();
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
         chunk(std::integral_constant<int, 13>{});
         chunk(std::integral_constant<int, 14>{});
         chunk(std::integral_constant<int, 15>{});
-        if (!(dbg & 16)) epilogue(p);
+        epilogue(p);
     }
     CW_WAIT(P, 0);                                   // the look-ahead reads of the chunk after the last
     cw_wait_vm<0>();                                 // the tail's pieces still target this workgroup's LDS
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       __bf16 *__restrict__ y, int npar, int dbg) {
+                                                       __bf16 *__restrict__ y, int npar) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
         chunk(std::integral_constant<int, 13>{});
         chunk(std::integral_constant<int, 14>{});
         chunk(std::integral_constant<int, 15>{});
-        if (!(dbg & 16)) epilogue(p);
+        epilogue(p);
     }
     CW16_WAIT(P, 0);
     cw_wait_vm<0>();
@@ -456,8 +458,6 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
     }
-    const char *de = getenv("VV_CTW_DBG");          // timing ablations only (wrong results): 16 no epilogue
-    const int dbg = de ? atoi(de) : 0;
     const char *se = getenv("VV_CTW_SHAPE");        // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
     const bool shape16 = !se || atoi(se) != 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -471,10 +471,10 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
         (void)attr;
         if (shape16)
             VV_LAUNCH(ctw16_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
-                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
+                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps);
         else
             VV_LAUNCH(ctw_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
-                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps, dbg);
+                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps);
     };
     switch (act) {
         case VV_ACT_ELU: launch(std::integral_constant<int, VV_ACT_ELU>{}); break;
