@@ -125,6 +125,34 @@ __global__ void pack_conv_k4s1_meanpool_kernel(const float *__restrict__ w, T *_
 }
 
 template <typename T>
+__global__ void pack_conv_k4s1_full_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
+    // out[(o,co)][(i,ci)] = w[i - o + 1][ci][co] (0 when a tap index leaves 0..3): the final encoder conv (k4 s1 SAME, pad 1 before /
+    // 2 after) position by position, for the pooling modes that are not linear (final_pool = 'max')
+    const int S3 = side * side * side, K = S3 * cin;
+    const size_t total = (size_t)S3 * cout * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K);
+        const int n = (int)(idx / K);
+        const int o = n / cout, co = n % cout;
+        const int i = k / cin, ci = k % cin;
+        const int td = i / (side * side) - o / (side * side) + 1, th = (i / side) % side - (o / side) % side + 1, tw = i % side - o % side + 1;
+        const bool ok = td >= 0 && td <= 3 && th >= 0 && th <= 3 && tw >= 0 && tw <= 3;
+        vv_store(out, idx, ok ? w[((size_t)((td * 4 + th) * 4 + tw) * cin + ci) * cout + co] : 0.f);
+    }
+}
+
+// out[b][c] = max over positions p of x[b][p][c] (tf.reduce_max over the spatial axes, autoencoder3D.py:92-93)
+__global__ void max_over_positions_kernel(const float *__restrict__ x, float *__restrict__ out, int batch, int npos, int channels) {
+    const size_t total = (size_t)batch * channels;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / channels, c = idx % channels;
+        float m = x[(b * npos) * channels + c];
+        for (int p = 1; p < npos; ++p) m = fmaxf(m, x[(b * npos + p) * channels + c]);
+        out[idx] = m;
+    }
+}
+
+template <typename T>
 __global__ void pack_convT_k4s1_dense_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
     // out[(o,co)][(j,ci)] = w[o - j + 1][co][ci] (0 when a tap index leaves 0..3)
     const int S3 = side * side * side, K = S3 * cin;
@@ -319,6 +347,20 @@ VV_EXPORT int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int
                                          void *stream) {
     if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
     VV_PACK_DISPATCH(pack_conv_k4s1_meanpool_kernel, (size_t)side * side * side * cin * cout, side, cin, cout);
+}
+
+VV_EXPORT int vv_pack_conv_k4s1_full(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream) {
+    if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
+    const size_t s3 = (size_t)side * side * side;
+    VV_PACK_DISPATCH(pack_conv_k4s1_full_kernel, s3 * cout * s3 * cin, side, cin, cout);
+}
+
+VV_EXPORT int vv_max_over_positions(const float *x, float *out, int batch, int npos, int channels, void *stream) {
+    if (!x || !out) return VV_ERR_NULL;
+    if (batch <= 0 || npos <= 0 || channels <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(max_over_positions_kernel, dim3(grid_for((size_t)batch * channels)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out,
+              batch, npos, channels);
+    return vv_launch_status();
 }
 
 VV_EXPORT int vv_pack_convT_k4s1_dense(const float *w_keras, void *packed, int side, int cin, int cout, int dtype,

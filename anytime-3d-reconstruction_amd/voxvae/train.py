@@ -140,6 +140,9 @@ class Trainer:
             raise ValueError('encoder and decoder engines must share one activation dtype')
         if dec.fp8 or (enc is not None and enc.fp8):
             raise ValueError("fit() runs in 'f32' or 'bf16'; 'fp8' is an inference mode (quantised weight images)")
+        if enc is not None and getattr(enc, 'pool_max', False):
+            raise NotImplementedError("fit() with final_pool='max': the training step folds the mean pool into the last conv's panel; "
+                                      "no reference config trains with the max pool")
         # 'f32': everything on the exact-f32 MFMA path (parity mode).  'bf16': mixed precision -- activations, their
         # gradients and the MFMA operands in bf16, float32 master weights / Adam moments / BatchNorm statistics / losses,
         # weight gradients accumulated in float32 (f32 MFMA over widened operands).
@@ -383,6 +386,8 @@ class Trainer:
         return stats, metrics, aux
 
     def _encoder_forward(self, x, B):
+        if getattr(self.enc, 'pool_max', False):
+            raise NotImplementedError("training-mode forward with final_pool='max'")
         enc, st, dt = self.enc, _st(), self.dt
         D, fe, act = enc.D, enc.filters, enc.act
         # ---------------- encoder forward (raw conv -> batch stats -> BN + act)

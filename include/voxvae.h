@@ -53,6 +53,11 @@ int vv_pack_convT_k4s2(const float *w_keras, void *packed, int cin, int cout, in
 /* Final encoder Conv3D k4 s1 SAME (pad 1/2) followed by the spatial mean (autoencoder3D.py:86-91) is linear in
  * its input: packed [Cout][S^3*Cin] with W_eff[i] = (1/S^3) * sum_o w[i - o + 1]  (S = input side). */
 int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);
+/* The same final encoder conv position by position, for final_pool = 'max' (autoencoder3D.py:92-93: tf.reduce_max is not linear):
+ * packed [S^3*Cout][S^3*Cin], row (o, co), column (i, ci) = w[i - o + 1][ci][co] (0 outside the 4 taps); a vv_dense_fwd with this
+ * panel gives the conv output [B][S^3][Cout], vv_max_over_positions the pooled [B][Cout]. */
+int vv_pack_conv_k4s1_full(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);
+int vv_max_over_positions(const float *x, float *out, int batch, int npos, int channels, void *stream);
 /* First decoder Conv3DTranspose k4 s1 SAME on the S^3 x Cin seed (autoencoder3D.py:127-128, first loop
  * iteration) as one dense panel: packed [S^3*Cout][S^3*Cin], row (o,co), col (j,ci) = w[o - j + 1][co][ci]. */
 int vv_pack_convT_k4s1_dense(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);

@@ -74,7 +74,7 @@ def bn_act_(x, p, prefix, act):
 
 
 def encoder3D_forward(structure, p, x):
-    """autoencoder3D.py:72-102, inference mode, average pool."""
+    """autoencoder3D.py:72-102, inference mode, average or max pool."""
     h = _f32(x)
     fl, st = structure['filter_num_list'], structure['strides_list']
     for i in range(len(fl) - 1):
@@ -82,6 +82,8 @@ def encoder3D_forward(structure, p, x):
         bn_act_(h, p, 'bn%d' % i, structure['activation'])
     i = len(fl) - 1
     h = conv3d_same(h, p['conv%d/kernel' % i], st[i])
+    if structure['final_pool'] == 'max':                  # autoencoder3D.py:92-93 (tf.reduce_max over the spatial axes)
+        return np.ascontiguousarray(h.max(axis=(1, 2, 3)), dtype=np.float32)
     assert structure['final_pool'] == 'average'
     B, S, C = h.shape[0], h.shape[1] ** 3, h.shape[4]
     y = np.empty((B, C), np.float32)

@@ -668,3 +668,41 @@ def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
         np.testing.assert_array_equal(p16, ref_pred.astype(np.float16))
     finally:
         hostio.set_prediction_host_dtype('float32')
+
+
+@pytest.mark.parametrize('dtype,D', [('f32', 32), ('bf16', 32), ('f32', 16)])
+def test_encoder_final_pool_max(dtype, D):
+    """final_pool = 'max' (reference autoencoder3D.py:92-93): tf.reduce_max is not linear, so the last conv runs position by
+    position (vv_pack_conv_k4s1_full + vv_dense_fwd) and vv_max_over_positions pools it; through the model class (getLatent,
+    getEval) against the CPU oracle.  fit() refuses (no reference config trains with it)."""
+    import voxvae
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype(dtype)
+    voxvae.set_default_device('cuda:0')
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(D, 64, True)
+    cfg['encoder']['final_pool'] = 'max'
+    ep, dp = syn.make_encoder_params(cfg['encoder']), syn.make_decoder_params(cfg['decoder'])
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(ep)
+    m._decoder.set_weights_dict(dp)
+    B = 5
+    x, eps = syn.make_voxels(B, D, seed=41), syn.make_eps(B, 64, seed=42)
+    ref = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
+    enc_out = np.array(m._encoder(x))
+    tol = 2e-5 if dtype == 'f32' else 3e-2
+    np.testing.assert_allclose(enc_out, ref['enc_out'], rtol=0, atol=tol * max(1.0, np.abs(ref['enc_out']).max()))
+    z = m.getLatent(x, _eps=eps)
+    np.testing.assert_allclose(z, ref['z'], rtol=0, atol=tol * max(1.0, np.abs(ref['z']).max()))
+    out = m.getEval(inputs=(x, x, syn.make_onehot(B, 40)), category_vectors=syn.make_category_vectors(40, 64), missing_prob=0.0, _eps=eps)
+    if dtype == 'f32':
+        np.testing.assert_allclose(np.array(out[0]), ref['probs'], atol=2.5e-4)
+        assert abs(float(out[1]) - ref['bce'].mean()) <= 2e-4 * ref['bce'].mean()
+    else:
+        s = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
+        yh, yt = np.array(out[0]).reshape(B, -1) >= 0.5, x.reshape(B, -1) > 0.5
+        iou = (yh & yt).sum(1) / np.maximum((yh | yt).sum(1), 1)
+        assert abs(iou.mean() - s.mean()) <= 1e-3
+    with pytest.raises(NotImplementedError):
+        m.fit((x, x))

@@ -214,3 +214,17 @@ def test_c_oracle_two_pass_get_eval_matches_golden(name):
     np.testing.assert_allclose(r['bce'], g['p5_bce'], rtol=2e-6)
     np.testing.assert_allclose(r['bce_c'], g['p5_bce_c'], rtol=2e-6)
     assert abs(r['acc'] - g['p5_scalars'][3]) < 1e-12 and abs(r['acc_c'] - g['p5_scalars'][7]) < 1e-12
+
+
+def test_max_pool_encoder_c_vs_numpy():
+    """final_pool = 'max' (reference autoencoder3D.py:92-93): the fp32 C composition against the float64 definition."""
+    cfg = syn.make_config(32, 8, True)                   # last feature map 2^3: the two pools differ
+    cfg['encoder']['final_pool'] = 'max'
+    cfg['encoder']['filter_num_list'] = [8, 8, 16, 16, 16]
+    ep = syn.make_encoder_params(cfg['encoder'])
+    x = syn.make_voxels(2, 32, seed=5)
+    ref = no.encoder3D_forward(cfg['encoder'], ep, x.astype(np.float64))
+    got = co.encoder3D_forward(cfg['encoder'], ep, x)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=5e-6)
+    cfg['encoder']['final_pool'] = 'average'
+    assert np.abs(no.encoder3D_forward(cfg['encoder'], ep, x.astype(np.float64)) - ref).max() > 1e-3     # the two pools differ
