@@ -261,13 +261,17 @@ __global__ __launch_bounds__(256) void final_bce_mfma_kernel(const __bf16 *__res
 // P rows are dense (32 taps = 8 quads of 16 B); quad q of the row of halo cell (zh, zw) sits at slot q ^ (zw & 7): the gather reads
 // whole quads with ds_read_b128 and this slot key makes every one of its lane groups conflict-free (exhaustive search over
 // a*zh + b*zw keys and pitches 32 / 36 / 40: profiles/microbench/d5_swz.py; the dword gathers of rounds 1-2 at pitch 36 were 4-way).
-constexpr int SW_ROWS = 100, SW_XB = 13 * 1024, SW_NX = 2, SW_PP = 32, SW_PSZ = 100 * SW_PP;   // X slot bytes (104 rows); P row pitch / buffer floats
+#ifndef VV_SW_DEPTH
+#define VV_SW_DEPTH 1            // input planes in flight ahead of the one being multiplied (ring = depth + 1 slots)
+#endif
+constexpr int SW_DEPTH = VV_SW_DEPTH;
+constexpr int SW_ROWS = 100, SW_XB = 13 * 1024, SW_NX = SW_DEPTH + 1, SW_PP = 32, SW_PSZ = 100 * SW_PP;   // X slot bytes (104 rows); P row pitch / buffer floats
 // LDS: 2 plane slots + 1 KiB sink + PL + PH = 53,248 B (+ 64 B of static sums): THREE workgroups per CU (rounds 1-2: 73.6 KB, two).
 // The 4th MFMA row tile reads 24 rows past a plane slot (into the next slot / the sink and the head of PL): whatever it finds only
 // reaches accumulator rows >= 104, which are never published.
 constexpr int SW_LDS = SW_NX * SW_XB + 1024 + 2 * SW_PSZ * 4;
 
-__global__ __launch_bounds__(256, 3) void final_bce_sweep_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(256, SW_DEPTH == 1 ? 3 : 2) void final_bce_sweep_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
                                                                  const float *__restrict__ target, float *__restrict__ probs,
                                                                  float *__restrict__ logits, float *__restrict__ partials,
                                                                  int din_log2, unsigned x_bytes, float gamma, float epsilon) {
@@ -366,13 +370,14 @@ __global__ __launch_bounds__(256, 3) void final_bce_sweep_kernel(const __bf16 *_
     __syncthreads();                                             // ... for every wave
     f32x16 acc[2];
     mfma_plane(0, acc);
-    stage(1, 1);
-    __syncthreads();                                             // slot 0 may be refilled (plane 2) from the first step on
+#pragma unroll
+    for (int k = 1; k <= SW_DEPTH; ++k) stage(k, k);
+    __syncthreads();                                             // slot 0 may be refilled from the first step on
 
     // (Unrolling this loop by two with the step parity as a compile-time constant -- ring slot and P buffer addresses folded
     // into the instructions -- is worth 2 % (53.5 vs 54.7 us) in the clean kernel; with the ablation switches still compiled in
     // it returned a low loss sum at B = 256 with exact logits and counts, which is not understood: not used.)
-    int oldh = 0;
+    int oldh = 0;                                                // ring slot of plane d
 #pragma unroll 1
     for (int d = 0; d <= n; ++d) {
         // weights-first: lane = cell row, registers walk the taps of the half; quad g = taps 8g + 4fh .. +3 = the four tw
@@ -407,12 +412,15 @@ __global__ __launch_bounds__(256, 3) void final_bce_sweep_kernel(const __bf16 *_
         // system-scope flat load with an immediate vmcnt(0).
         float2 y;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
-        stage(d + 2, oldh);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // plane d+1 (issued a step ago) has landed
+        stage(d + 1 + SW_DEPTH, oldh);
+        // depth 1: [plane d+1 x4][stores d-1][y d][plane d+2 x4] -> all but the newest 5.  depth 2: plane d+1 is followed by
+        // stores d-2 (0..2), y d-1, plane d+2 x4, stores d-1 (0..2), y d, plane d+3 x4 = 10..14 operations -> all but the newest 10
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW_DEPTH == 1 ? 5 : 10) : "memory");         // plane d+1 has landed
         __syncthreads();                                         // ... for every wave; P_d is published
 
         f32x16 acc_next[2];
-        mfma_plane(oldh ^ 1, acc_next);
+        const int nexth = oldh + 1 == SW_NX ? 0 : oldh + 1;      // ring slot of plane d+1
+        mfma_plane(nexth, acc_next);
 
         // gather: per ah the tap quads (tw 0..3) of the three cells mw, mw+1, mw+2 -- ds_read_b128, conflict-free.  The td in {0,1}
         // half of P_d (PL) completes the output planes od = 2d - 1 + sl together with the td in {2,3} half of P_{d-1}, which was
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(256, 3) void final_bce_sweep_kernel(const __bf16 *_
         }
         acc[0] = acc_next[0];
         acc[1] = acc_next[1];
-        oldh ^= 1;
+        oldh = nexth;
         __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes

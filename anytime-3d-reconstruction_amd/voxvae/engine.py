@@ -485,7 +485,7 @@ class DecoderEngine(_EngineBase):
                            L.ptr(pk['shift%d' % i]), L.ptr(o), B, side, f[i - 1], f[i], self.act, self.dt, st)
                 h, side, hdt = o, 2 * side, self.dt
                 continue
-            if ('ws%d' % i) in pk and not nq and hdt == self.dt:
+            if ('ws%d' % i) in pk and hdt == self.dt:      # (an fp8 next layer converts this bf16 output itself: cheaper than the implicit GEMM)
                 o = self._empty(B, 2 * side, 2 * side, 2 * side, f[i])
                 if side == 2:
                     ws = self.ws.get(L.load().vv_convT3d_k4s2_pos_workspace_bytes(B, f[i - 1], f[i]))
