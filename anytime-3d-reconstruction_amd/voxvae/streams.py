@@ -3,24 +3,25 @@
 One evaluation step is a chain of 13 dependent launches; several of them (the 4^3 <-> 2^3 layers, the latent tail, the
 reduction passes) are latency-bound and leave most of the chip idle, and every launch has a ramp-up and a tail.  Batches are
 independent of each other (reference test loop: test_modelnet_VAE.py:114-130 calls getEval batch after batch), so the next
-batch can fill those holes if it runs on its own stream.  Each stream needs its own engine replica: the engines own split-K /
-slab workspaces that a second in-flight step would overwrite.  Weights are replicated (53 MB per replica in bf16).
+batch can fill those holes if it runs on its own stream.  The engines keep one split-K / slab workspace PER STREAM (round 3),
+so ONE model serves every stream (rounds 1-2 replicated the model per stream, 53 MB of bf16 weights each; `replicas=True` still does).
 
     ev = StreamedEvaluator(lambda: build_model(), streams=2)
     for x, y, eps in batches:
         outs.append(ev.submit(x, y, eps))      # returns the step's device tensors; asynchronous
     ev.synchronize()
 
-Measured on MI355X (32^3, batch 256, bf16): 0.570 ms/step on one stream, 0.496 on two, 0.493 on three.
+Measured on MI355X (32^3, batch 256, bf16; profiles/microbench/mb_streams3.py, four interleaved repetitions in one process):
+0.535 ms/step on one stream, 0.478-0.480 on two, 0.463-0.469 on three, 0.484-0.486 on four.
 """
 import torch
 
 
 class StreamedEvaluator:
-    def __init__(self, model_factory, streams=2, device=None):
+    def __init__(self, model_factory, streams=3, device=None, replicas=False):
         if streams < 1:
             raise ValueError('streams must be >= 1')
-        self.models = [model_factory() for _ in range(streams)]
+        self.models = [model_factory() for _ in range(streams)] if replicas else [model_factory()] * streams
         self.device = torch.device(device) if device is not None else self.models[0]._device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)] if streams > 1 else [None]
         self._next = 0

@@ -8,8 +8,9 @@ configs[1] (ModelNet40 VAE, 32^3, batch 256, bf16); synthetic voxels + random-in
     python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32|fp8] [--mode eval|train] [--streams S]
 
 Scheduling: by default the K steps (independent batches, as in the reference's test loop test_modelnet_VAE.py:114-130) are
-issued round-robin on 2 HIP streams with one engine replica per stream (voxvae/streams.py): the latency-bound launches and the
-ramp / tail of every launch of one batch are filled by the other batch's kernels (+15 % on MI355X).  Every step still runs the
+issued round-robin on 3 HIP streams over ONE model (voxvae/streams.py; the engines keep a workspace per stream): the latency-bound
+launches and the ramp / tail of every launch of one batch are filled by the other batches' kernels (+15 % on MI355X; two streams:
++12 %, four: +10 %).  Every step still runs the
 whole path on its own 256-batch inside the timed region; `single_stream` in the line is the one-batch-at-a-time rate of the
 same process, and the per-kernel roofline is taken from those launches (a kernel that shares the chip with another stream's
 kernel while its events are open says nothing about the kernel; that duration is reported as `roofline.in_timed_region`).
@@ -65,8 +66,8 @@ def parse(argv=None):
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
                     help="'eval' = the BASELINE.json headline (default); 'train' = fit() steps (gradients all-reduced over RCCL for N>1)")
-    ap.add_argument('--streams', type=int, default=2,
-                    help='HIP streams per GPU: independent batches are issued round-robin, one engine replica per stream (1 = one batch at a time)')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='HIP streams per GPU: independent batches are issued round-robin on them, one model (the engines keep a workspace per stream); 1 = one batch at a time')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="process-group backend ('nccl' = RCCL; 'gloo' with --dry-run only)")
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective rehearsal without a GPU: ranks fabricate per-rank metrics and run the same reduction code')
@@ -580,7 +581,7 @@ def main():
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world,
                        'parallelism': 'batch-sharded x%d, no data-path collective; 8 metric scalars all-reduced once' % world,
                        'streams_per_gpu': nstreams,
-                       'scheduling': ('independent 256-batches issued round-robin on %d HIP streams, one engine replica (weights + workspaces) per stream' % nstreams)
+                       'scheduling': ('independent %d-batches issued round-robin on %d HIP streams, one model (a workspace per stream)' % (a.batch, nstreams))
                                      if nstreams > 1 else 'one batch at a time on one stream'},
             'rccl_world_size': nranks, 'process_group': dist.get_backend() if dist is not None else None,
             'global_metrics': global_metrics(sums),

@@ -18,5 +18,5 @@ echo "[collect] pmc sq1"; rocprofv3 --kernel-trace --output-format csv -d $out/s
 echo "[collect] pmc sq2"; rocprofv3 --kernel-trace --output-format csv -d $out/sq2 -o t --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM -- python3 bench.py $args > $out/bench_sq2.json 2> $out/sq2.err
 echo "[collect] pmc fetch"; rocprofv3 --kernel-trace --output-format csv -d $out/fetch -o t --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py $args > $out/bench_fetch.json 2> $out/fetch.err
 echo "[collect] pmc write"; rocprofv3 --kernel-trace --output-format csv -d $out/write -o t --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 bench.py $args > $out/bench_write.json 2> $out/write.err
-echo "[collect] kernel trace, default scheduling (2 streams)"; rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace2 -o t -- python3 bench.py --steps 20 --warmup 5 --cpu-samples 0 --no-breakdown > $out/bench_trace2.json 2> $out/trace2.err
+echo "[collect] kernel trace, default scheduling (3 streams since round 3)"; rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace2 -o t -- python3 bench.py --steps 20 --warmup 5 --cpu-samples 0 --no-breakdown > $out/bench_trace2.json 2> $out/trace2.err
 find $out -name '*.csv' | sort

@@ -530,11 +530,11 @@ def test_surveyed_edge_cases():
     np.testing.assert_allclose(z[2], 0.25, atol=1e-7)
 
 
-@pytest.mark.parametrize('B,nb,ns', [(48, 7, 3), (256, 6, 2)])      # 256 x 2 streams = bench.py's default: kernels of two steps share CUs
-def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns):
-    """voxvae.streams.StreamedEvaluator: independent batches issued round-robin on 2 or 3 HIP streams (one engine replica each) give
-    bit-identical per-sample sums, metrics and KL to the same batches run one at a time on one stream -- the replicas share
-    nothing but the (read-only) inputs."""
+@pytest.mark.parametrize('B,nb,ns,replicas', [(48, 7, 3, False), (256, 7, 3, False), (256, 6, 2, True)])   # 256 x 3 streams, one model = bench.py's default
+def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns, replicas):
+    """voxvae.streams.StreamedEvaluator: independent batches issued round-robin on 2 or 3 HIP streams give bit-identical per-sample
+    sums, metrics and KL to the same batches run one at a time on one stream -- with ONE model serving every stream (the engines
+    keep a split-K / slab workspace per stream: kernels of three steps share the CUs and nothing else) and with a replica per stream."""
     import contextlib
     import sys
     import voxvae
@@ -559,7 +559,8 @@ def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns):
     ref_model = build()
     ref = [ref_model.eval_forward_device(x, x, e) for x, e in batches]
     torch.cuda.synchronize()
-    ev = StreamedEvaluator(build, streams=ns, device=DEV)
+    ev = StreamedEvaluator(build, streams=ns, device=DEV, replicas=replicas)
+    assert (len(set(id(m) for m in ev.models)) == ns) == replicas
     got = [ev.submit(x, x, e) for x, e in batches]
     ev.synchronize()
     for (p0, s0, m0, k0), (p1, s1, m1, k1) in zip(ref, got):
