@@ -136,8 +136,11 @@ def test_builders_and_checkpoints(tmp_path):
     assert np.array(e).shape == (2, 128)
     p = dec(np.array(e)[:, :64])
     assert np.array(p).shape == (2, 16, 16, 16, 1) and 0 <= np.array(p).min() and np.array(p).max() <= 1
-    with pytest.raises(NotImplementedError):
-        bad = dict(cfg['encoder']); bad['final_pool'] = 'max'
+    with pytest.raises(NotImplementedError):                 # an unknown pooling mode ('average' and 'max' are the reference's two)
+        bad = dict(cfg['encoder']); bad['final_pool'] = 'median'
+        ae3D.encoder3D(bad)
+    with pytest.raises(NotImplementedError):                 # filter sizes other than 4: no reference config
+        bad = dict(cfg['encoder']); bad['filter_size_list'] = [3, 3, 3, 3, 3]
         ae3D.encoder3D(bad)
     import src.module.nolbo as nolbo
     m1 = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
