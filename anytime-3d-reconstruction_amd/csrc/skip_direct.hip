@@ -73,14 +73,41 @@ __global__ void sd_pack_conv_kernel(const float *__restrict__ w, __bf16 *__restr
     }
 }
 
+// The same image through a 64 x 64 LDS tile (cout % 64 == 0): block (t * NC + c, n block) reads 64 k-rows x 64 n with 16-byte loads
+// along n and writes 64 n-rows of 64 consecutive k (128 B) -- both sides coalesced.  The element-wise form above reads with a
+// stride of cout floats (8x the bytes past L2) and took 30 us on the 8 M-element layer; the training step packs per use.
+__global__ __launch_bounds__(256) void sd_pack_conv_tiled_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int kb = blockIdx.x, n0 = blockIdx.y * 64;             // kb = t * NC + c: Keras rows kb * 64 .. + 63 (row = t * cin + c * 64 + k)
+    const int c4 = tid & 15, r = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kl = r + 16 * j;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + ((size_t)kb * 64 + kl) * cout + n0 + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[kl][4 * c4 + e] = v[e];
+    }
+    __syncthreads();
+    const int col = tid >> 2, kq = (tid & 3) * 16;
+    __bf16 *dst = out + ((size_t)kb * cout + n0 + col) * 64 + kq;
+#pragma unroll
+    for (int e = 0; e < 16; e += 8) {
+        bf16x8 o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = static_cast<__bf16>(tile[kq + e + u][col]);
+        *reinterpret_cast<bf16x8 *>(dst + e) = o;
+    }
+}
+
 // out[((((p*8 + a)*NC + c)*cout + n)*64 + k] = w[(t(p,a)*cout + n)*cin + c*64 + k],  t = 1 - p + 2a per axis
-// (Keras Conv3DTranspose [kd,kh,kw,Cout,Cin])
+// (Keras Conv3DTranspose [kd,kh,kw,Cout,Cin]); 8 consecutive k per thread: two 16-byte reads, one 16-byte write
 __global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
     const int NC = cin / 64;
-    const long total = (long)64 * cin * cout;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i & 63);
-        long r = i >> 6;
+    const long total8 = (long)8 * cin * cout;
+    for (long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8; i8 += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i8 & 7) * 8;
+        long r = i8 >> 3;
         const int n = (int)(r % cout); r /= cout;
         const int c = (int)(r % NC); r /= NC;
         const int a = (int)(r & 7), p = (int)(r >> 3);
@@ -88,7 +115,12 @@ __global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__rest
         const int th = 1 - ((p >> 1) & 1) + 2 * ((a >> 1) & 1);
         const int tw = 1 - (p & 1) + 2 * (a & 1);
         const int t = (td * 4 + th) * 4 + tw;
-        out[i] = static_cast<__bf16>(w[((size_t)t * cout + n) * cin + c * 64 + k]);
+        const float *src = w + ((size_t)t * cout + n) * cin + c * 64 + k;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[u] = static_cast<__bf16>(v0[u]); o[4 + u] = static_cast<__bf16>(v1[u]); }
+        *reinterpret_cast<bf16x8 *>(out + i8 * 8) = o;
     }
 }
 
@@ -582,15 +614,20 @@ VV_EXPORT int vv_convT3d_k4s2_skip_supported(int side, int cin, int cout, int dt
 VV_EXPORT int vv_pack_conv_k4_skip(const float *w_keras, void *packed, int cin, int cout, void *stream) {
     if (!w_keras || !packed) return VV_ERR_NULL;
     if (cin <= 0 || cout <= 0 || cin % 64) return VV_ERR_SHAPE;
-    VV_LAUNCH(sd_pack_conv_kernel, dim3(sd_grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
-              reinterpret_cast<__bf16 *>(packed), cin, cout);
+    if (cout % 64 == 0 && vv_aligned16(w_keras) && vv_aligned16(packed))
+        VV_LAUNCH(sd_pack_conv_tiled_kernel, dim3(64 * (cin / 64), cout / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+                  reinterpret_cast<__bf16 *>(packed), cin, cout);
+    else
+        VV_LAUNCH(sd_pack_conv_kernel, dim3(sd_grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+                  reinterpret_cast<__bf16 *>(packed), cin, cout);
     return vv_launch_status();
 }
 
 VV_EXPORT int vv_pack_convT_k4s2_skip(const float *w_keras, void *packed, int cin, int cout, void *stream) {
     if (!w_keras || !packed) return VV_ERR_NULL;
     if (cin <= 0 || cout <= 0 || cin % 64) return VV_ERR_SHAPE;
-    VV_LAUNCH(sd_pack_convT_kernel, dim3(sd_grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
+    if (!vv_aligned16(w_keras) || !vv_aligned16(packed)) return VV_ERR_ALIGN;
+    VV_LAUNCH(sd_pack_convT_kernel, dim3(sd_grid_1d((long)8 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
               reinterpret_cast<__bf16 *>(packed), cin, cout);
     return vv_launch_status();
 }
