@@ -105,10 +105,10 @@ def to_host(t, big=1 << 20):
 class HostPrediction(object):
     """What the chunked getEval returns for `pred`: the host array is already there (its download ran under the kernels of the
     next chunk); the device chunks are kept for callers that want the tensor."""
-    __slots__ = ('host', 'chunks')
+    __slots__ = ('host', 'chunks', '_handed_out')
 
     def __init__(self, host, chunks):
-        self.host, self.chunks = host, chunks
+        self.host, self.chunks, self._handed_out = host, chunks, False
 
     @property
     def shape(self):
@@ -129,7 +129,14 @@ class HostPrediction(object):
         return self.host
 
     def __array__(self, dtype=None, copy=None):
-        return self.host.astype(dtype) if dtype is not None and np.dtype(dtype) != self.host.dtype else self.host
+        # np.array(pred) asks for a copy: the FIRST caller gets the pinned-block array itself (nobody else writes to it; that
+        # is the whole point of downloading into it), later callers and explicit dtype changes get real copies
+        if dtype is not None and np.dtype(dtype) != self.host.dtype:
+            return self.host.astype(dtype)
+        if copy is False or not self._handed_out:
+            self._handed_out = self._handed_out or copy is not False
+            return self.host
+        return self.host.copy()
 
     def __len__(self):
         return self.host.shape[0]
