@@ -449,11 +449,13 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
     if (!x || !w_skip || !y) return VV_ERR_NULL;
     if (!vv_convT3d_k4s2_whole_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
     if (!vv_aligned16(x) || !vv_aligned16(w_skip) || !vv_aligned16(y)) return VV_ERR_ALIGN;
-    // two rounds of workgroups per CU rather than one: measured on 3 devices, the step on two streams is 2-4 % faster with the
-    // parities split in two at batch 256 (0.500 vs 0.515-0.521 ms; the other stream's kernels get CUs between the rounds),
-    // one batch at a time 1.5 % slower (0.574 vs 0.566)
+    // One workgroup per sample once the batch fills the chip (one round of 256), else the parities are split until it does.
+    // History: with TWO streams two rounds (every sample loaded twice) were 2-4 % faster at batch 256 (the other stream's kernels got
+    // CUs between the rounds); with the THREE streams of round 3 one round is as fast or faster (0.470-0.473 vs 0.472-0.485 ms/step,
+    // profiles/microbench/ab_ps3.sh), 1.5 % faster one batch at a time, and reads every sample once: HBM traffic 1.30x -> ~1.05x the
+    // algorithmic bytes.
     int ps = 1;
-    while (ps < 8 && (long)batch * ps < 512) ps *= 2;
+    while (ps < 8 && (long)batch * ps < 256) ps *= 2;
     if (const char *e = getenv("VV_CTW_PS")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
