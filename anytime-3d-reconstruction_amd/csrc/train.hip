@@ -428,10 +428,14 @@ struct WgradBArgs {
     unsigned a_bytes, g_bytes;
 };
 
-template <int AMODE>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0;
+template <int AMODE, bool ONE = false>      // 0: A[r][m] dense (pitch lda); 1: A[r][(t,ci)] = src[b, 2o-1+t, ci], cin % 64 == 0;
                           // 2: A[r][t] = src[b, 2o-1+t] of a single-channel float32 grid (M = 64), built in registers
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) {
+__global__ __launch_bounds__(256, ONE ? 4 : 2) void wgrad_bf16_kernel(const WgradBArgs a) {
     constexpr int BM = 128, BN = 128, BR = 64, OPB = BR * 128 * 2;        // one operand chunk: 16 KiB
+    // ONE (AMODE 2 with N <= 64, chosen at launch): a single 64 x 64 output tile.  Only column blocks 0, 1 of either operand exist, so a
+    // stage is 16 KiB (A | G, 8 KiB each) instead of 32, the whole ring 32 KiB, and FOUR workgroups fit a CU: the kernel waits for one
+    // chunk at a time (vmcnt(0) + barrier per 64 rows), so what it achieves is set by the chunks in flight per CU.
+    constexpr int STG = ONE ? 16384 : 2 * OPB, GOFF = ONE ? 8192 : OPB;
     extern __shared__ __attribute__((aligned(16))) char smem[];           // [2 stages][A | G]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -442,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     const long r_begin = (long)blockIdx.y * a.rows_per_split;
     const long r_end = r_begin + a.rows_per_split < a.R ? r_begin + a.rows_per_split : a.R;
     const int li = a.din_log2, n = 1 << li, lo = li - 1, omsk = (1 << lo) - 1;
+    constexpr bool one_tile = ONE;                          // single-channel layer, one 64 x 64 output tile: K split over the waves (below)
     const u32x4 rsa = vv_make_rsrc(a.A, a.a_bytes), rsg = vv_make_rsrc(a.G, a.g_bytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
@@ -451,6 +456,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = wave * 4 + i, cb = piece >> 2, rg = piece & 3;
+            if (one_tile && cb >= 2) continue;             // single-channel layers with <= 64 channels: column blocks 2, 3 are never read
             const long r = rc + rg * 16 + prow;
             const int mcol = m0 + cb * 32, ncol = n0 + cb * 32;
             unsigned va = 0xFFFFFFF0u, vg = 0xFFFFFFF0u;
@@ -469,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
                 }
                 if (ncol < a.N) vg = (unsigned)((r * a.N + ncol + pch * 8) * 2);
             }
-            const unsigned dst = lds0 + st * (2 * OPB) + cb * 4096 + rg * 1024;
+            const unsigned dst = lds0 + st * STG + cb * 4096 + rg * 1024;
             if (AMODE != 2) vv_dma16(rsa, va, dst);
-            vv_dma16(rsg, vg, dst + OPB);
+            vv_dma16(rsg, vg, dst + GOFF);
         }
     };
     // AMODE 2: thread = (chunk row tid >> 2, tap plane td = tid & 3) owns 16 taps (th, tw) = 32 bytes of the row.  The
@@ -504,11 +510,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[th >> 1][(th & 1) * 4 + e] = static_cast<__bf16>(v[e]);
         }
-        char *dst = smem + st * (2 * OPB) + (td >> 1) * 4096 + row * 64 + (td & 1) * 32;
+        char *dst = smem + st * STG + (td >> 1) * 4096 + row * 64 + (td & 1) * 32;
         *reinterpret_cast<bf16x8 *>(dst) = o[0];
         *reinterpret_cast<bf16x8 *>(dst + 16) = o[1];
     };
-    if (AMODE == 2) {                                      // taps 64..127 of the 128-wide tile do not exist: column blocks 2, 3 stay zero
+    if (AMODE == 2 && !ONE) {                              // taps 64..127 of the 128-wide tile do not exist: column blocks 2, 3 stay zero
         const bf16x8 z = {};
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x8 *>(smem + (tid >> 7) * (2 * OPB) + 8192 + ((tid & 127) * 4 + q) * 16) = z;
@@ -525,14 +531,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     // transposed-read address of this lane inside a column block, for k-step 0: row 8 fh + q, columns 16 (g & 1) + 4p
     const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const unsigned troff = ((g4 >> 1) * 8 + q4) * 64 + ((g4 & 1) * 16 + p4 * 4) * 2;
-    auto frag = [&](unsigned base) -> bf16x8 {       // base = operand + column block + k-step: rows +0..3 then +4..7
-        u32x2 lo2, hi2;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(lo2), "=&v"(hi2) : "v"(base + troff) : "memory");
-        u32x4 v = {lo2[0], lo2[1], hi2[0], hi2[1]};
-        return *reinterpret_cast<bf16x8 *>(&v);
-    };
-
     long rc = r_begin;
     int st = 0;
     if (rc < r_end) {
@@ -547,15 +545,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
             if (AMODE == 2) load_x(rc + BR);
             stage(rc + BR, st ^ 1);
         }
-        const unsigned sa = lds0 + st * (2 * OPB), sg = sa + OPB;
+        const unsigned sa = lds0 + st * STG, sg = sa + GOFF;
+        if (one_tile) {
+            // M = 64, N <= 64: ONE 64 x 64 tile.  The generic mapping (2 x 2 waves of 64 x 64 on a 128 x 128 tile) left three of the
+            // four waves multiplying zeros and the fourth one waiting for sixteen serialised fragment reads per chunk; here the
+            // four waves split the chunk's K (one 16-row k-step each), issue their eight transposed reads together, and their
+            // accumulators meet through LDS after the last chunk (in wave order: deterministic).
+            const unsigned ka = sa + wave * 1024 + troff, kg = sg + wave * 1024 + troff;
+            u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %2, %8 offset:4096\n\tds_read_b64_tr_b16 %3, %8 offset:4352\n\t"
+                         "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %6, %9 offset:4096\n\tds_read_b64_tr_b16 %7, %9 offset:4352\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(ka), "v"(kg) : "memory");
+            const u32x4 a0 = {r0[0], r0[1], r1[0], r1[1]}, a1 = {r2[0], r2[1], r3[0], r3[1]};
+            const u32x4 g0 = {r4[0], r4[1], r5[0], r5[1]}, g1 = {r6[0], r6[1], r7[0], r7[1]};
+            const bf16x8 fa[2] = {*reinterpret_cast<const bf16x8 *>(&a0), *reinterpret_cast<const bf16x8 *>(&a1)};
+            const bf16x8 fg[2] = {*reinterpret_cast<const bf16x8 *>(&g0), *reinterpret_cast<const bf16x8 *>(&g1)};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);   // D[m][n]
+        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fg[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                fa[t] = frag(sa + (wm * 2 + t) * 4096 + ks * 1024);
-                fg[t] = frag(sg + (wn * 2 + t) * 4096 + ks * 1024);
-            }
+            // the eight transposed reads of a k-step are issued together and waited for once (one wait per fragment serialised
+            // eight LDS round trips per k-step)
+            const unsigned ka = sa + wm * 8192 + ks * 1024 + troff, kg = sg + wn * 8192 + ks * 1024 + troff;
+            u32x2 r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %2, %8 offset:4096\n\tds_read_b64_tr_b16 %3, %8 offset:4352\n\t"
+                         "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:256\n\t"
+                         "ds_read_b64_tr_b16 %6, %9 offset:4096\n\tds_read_b64_tr_b16 %7, %9 offset:4352\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(ka), "v"(kg) : "memory");
+            const u32x4 a0 = {r0[0], r0[1], r1[0], r1[1]}, a1 = {r2[0], r2[1], r3[0], r3[1]};
+            const u32x4 g0 = {r4[0], r4[1], r5[0], r5[1]}, g1 = {r6[0], r6[1], r7[0], r7[1]};
+            const bf16x8 fa[2] = {*reinterpret_cast<const bf16x8 *>(&a0), *reinterpret_cast<const bf16x8 *>(&a1)};
+            const bf16x8 fg[2] = {*reinterpret_cast<const bf16x8 *>(&g0), *reinterpret_cast<const bf16x8 *>(&g1)};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -565,6 +591,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBArgs a) 
     }
     const int fr = lane & 31, fh = lane >> 5;
     float *slab = a.slabs + (size_t)blockIdx.y * a.M * a.N;
+    if (one_tile) {
+        // the four waves' accumulators meet in the 32 KiB of the ring: waves 0, 1 store, waves 2, 3 add on top (same lane -> same
+        // element), then every thread adds the two halves: (w0 + w2) + (w1 + w3), a fixed order
+        float *red = reinterpret_cast<float *>(smem) + (wave & 1) * 4096;
+        __syncthreads();                                     // every wave is done with the stages
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((wave >> 1) == pass) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            float *e = red + (i * 32 + (q & 3) + 8 * (q >> 2) + 4 * fh) * 64 + j * 32 + fr;
+                            *e = pass == 0 ? acc[i][j][q] : *e + acc[i][j][q];
+                        }
+            }
+            __syncthreads();
+        }
+        const float *r0 = reinterpret_cast<const float *>(smem);
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int m = idx >> 6, nn = idx & 63;
+            if (nn < a.N) slab[(size_t)m * a.N + nn] = r0[idx] + r0[4096 + idx];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -938,7 +991,8 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
         return true;
     }();
     (void)attr;
-    VV_LAUNCH((wgrad_bf16_kernel<AMODE>), dim3(tiles, p.splits), dim3(256), 65536, st, a);
+    if (AMODE == 2 && a.N <= 64) VV_LAUNCH((wgrad_bf16_kernel<2, true>), dim3(tiles, p.splits), dim3(256), 32768, st, a);
+    else VV_LAUNCH((wgrad_bf16_kernel<AMODE>), dim3(tiles, p.splits), dim3(256), 65536, st, a);
     const long n = (long)a.M * a.N;
     launch_wgrad_reduce(a.slabs, out, n, p.splits, 1.f, 0, st);
     return vv_launch_status();
