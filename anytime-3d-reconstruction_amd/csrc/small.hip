@@ -124,6 +124,46 @@ __global__ void pack_conv_k4s1_meanpool_kernel(const float *__restrict__ w, T *_
     }
 }
 
+// The same panel through a 64 x 64 LDS tile (cin % 64 == 0, cout % 64 == 0): block (input position i, 64 ci, 64 co) sums the valid
+// taps with 16-byte reads along co and writes 64 co-rows of 64 consecutive k -- both sides coalesced.  The element-wise form reads
+// with a stride of cout floats and took 20 us for the 4 M-element layer; the training step packs it twice per step.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_k4s1_meanpool_tiled_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
+    __shared__ float tile[64][65];
+    const int S3 = side * side * side, K = S3 * cin, tid = threadIdx.x;
+    const int nci = cin >> 6;
+    const int i = blockIdx.x / nci, ci0 = (blockIdx.x % nci) * 64, co0 = blockIdx.y * 64;
+    const int iw = i % side, ih = (i / side) % side, id = i / (side * side);
+    const int c4 = tid & 15, r = tid >> 4;
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int od = 0; od < side; ++od) {
+        const int td = id - od + 1;
+        if (td < 0 || td > 3) continue;
+        for (int oh = 0; oh < side; ++oh) {
+            const int th = ih - oh + 1;
+            if (th < 0 || th > 3) continue;
+            for (int ow = 0; ow < side; ++ow) {
+                const int tw = iw - ow + 1;
+                if (tw < 0 || tw > 3) continue;
+                const float *wt = w + ((size_t)((td * 4 + th) * 4 + tw) * cin + ci0) * cout + co0 + 4 * c4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += *reinterpret_cast<const f32x4 *>(wt + (size_t)(r + 16 * j) * cout);
+            }
+        }
+    }
+    const float inv = 1.0f / (float)S3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r + 16 * j][4 * c4 + e] = s[j][e] * inv;
+    __syncthreads();
+    const int col = tid >> 2, kq = (tid & 3) * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) vv_store(out, (size_t)(co0 + col) * K + (size_t)i * cin + ci0 + kq + e, tile[kq + e][col]);
+}
+
 template <typename T>
 __global__ void pack_conv_k4s1_full_kernel(const float *__restrict__ w, T *__restrict__ out, int side, int cin, int cout) {
     // out[(o,co)][(i,ci)] = w[i - o + 1][ci][co] (0 when a tap index leaves 0..3): the final encoder conv (k4 s1 SAME, pad 1 before /
@@ -346,6 +386,13 @@ VV_EXPORT int vv_pack_convT_k4s2(const float *w_keras, void *packed, int cin, in
 VV_EXPORT int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int side, int cin, int cout, int dtype,
                                          void *stream) {
     if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
+    if (w_keras && packed && cin % 64 == 0 && cout % 64 == 0 && (dtype == VV_F32 || dtype == VV_BF16) && vv_aligned16(w_keras)) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const dim3 grid(side * side * side * (cin / 64), cout / 64);
+        if (dtype == VV_BF16) VV_LAUNCH(pack_conv_k4s1_meanpool_tiled_kernel<__bf16>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<__bf16 *>(packed), side, cin, cout);
+        else VV_LAUNCH(pack_conv_k4s1_meanpool_tiled_kernel<float>, grid, dim3(256), 0, st, w_keras, reinterpret_cast<float *>(packed), side, cin, cout);
+        return vv_launch_status();
+    }
     VV_PACK_DISPATCH(pack_conv_k4s1_meanpool_kernel, (size_t)side * side * side * cin * cout, side, cin, cout);
 }
 

@@ -701,6 +701,47 @@ __global__ void unpack_meanpool_grad_kernel(const float *__restrict__ dpanel, fl
     }
 }
 
+// The same through a 64 x 64 LDS tile (cin % 64 == 0, cout % 64 == 0): block (tap t, 64 ci, 64 co) sums the valid (i, o) pairs with
+// 16-byte reads along ci (a dpanel row is contiguous in k = i * cin + ci) and writes dw rows contiguous in co.
+__global__ __launch_bounds__(256) void unpack_meanpool_grad_tiled_kernel(const float *__restrict__ dpanel, float *__restrict__ dw, int side, int cin, int cout) {
+    __shared__ float tile[64][65];
+    const int S3 = side * side * side, tid = threadIdx.x;
+    const int nci = cin >> 6;
+    const int t = blockIdx.x / nci, ci0 = (blockIdx.x % nci) * 64, co0 = blockIdx.y * 64;
+    const int td = t >> 4, th = (t >> 2) & 3, tw = t & 3;
+    const int c4 = tid & 15, r = tid >> 4;                 // ci quad, co row (16 per pass)
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int od = 0; od < side; ++od) {
+        const int id = od + td - 1;
+        if ((unsigned)id >= (unsigned)side) continue;
+        for (int oh = 0; oh < side; ++oh) {
+            const int ih = oh + th - 1;
+            if ((unsigned)ih >= (unsigned)side) continue;
+            for (int ow = 0; ow < side; ++ow) {
+                const int iw = ow + tw - 1;
+                if ((unsigned)iw >= (unsigned)side) continue;
+                const float *src = dpanel + (size_t)co0 * S3 * cin + (size_t)((id * side + ih) * side + iw) * cin + ci0 + 4 * c4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += *reinterpret_cast<const f32x4 *>(src + (size_t)(r + 16 * j) * S3 * cin);
+            }
+        }
+    }
+    const float inv = 1.0f / (float)S3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[4 * c4 + e][r + 16 * j] = s[j][e] * inv;      // [ci][co]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cil = r + 16 * j;
+        *reinterpret_cast<f32x4 *>(dw + ((size_t)t * cin + ci0 + cil) * cout + co0 + 4 * c4) =
+            f32x4{tile[cil][4 * c4], tile[cil][4 * c4 + 1], tile[cil][4 * c4 + 2], tile[cil][4 * c4 + 3]};
+    }
+}
+
 __global__ void unpack_convT_dense_grad_kernel(const float *__restrict__ dpanel, float *__restrict__ dw, int side, int cin, int cout) {
     // dw[t][co][ci] = sum_{(o,j) : o - j + 1 = t per axis} dpanel[(o,co)][(j,ci)]
     const int S3 = side * side * side, K = S3 * cin;
@@ -1063,6 +1104,11 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
 
 VV_EXPORT int vv_unpack_meanpool_grad(const float *dpanel, float *dw, int side, int cin, int cout, void *stream) {
     if (!dpanel || !dw) return VV_ERR_NULL;
+    if (cin % 64 == 0 && cout % 64 == 0 && side > 0 && vv_aligned16(dpanel) && vv_aligned16(dw)) {
+        VV_LAUNCH(unpack_meanpool_grad_tiled_kernel, dim3(64 * (cin / 64), cout / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dpanel, dw,
+                  side, cin, cout);
+        return vv_launch_status();
+    }
     VV_LAUNCH(unpack_meanpool_grad_kernel, dim3(grid_1d((long)64 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
               dpanel, dw, side, cin, cout);
     return vv_launch_status();
