@@ -416,6 +416,9 @@ class DecoderEngine(_EngineBase):
                   and (L.load().vv_convT3d_k4s2_skip_supported(side_i, f[i - 1], f[i], self.dt)
                        or L.load().vv_convT3d_k4s2_pos_supported(side_i, f[i - 1], f[i], self.dt))):
                 pk['w%d' % i] = None    # training step: the skip / position image is packed per use (voxvae/train.py: _convT)
+            elif (not q and not self._want_fold and direct and not os.environ.get('VV_NO_WHOLE') and not os.environ.get('VV_NO_DIRECT')
+                  and L.load().vv_convT3d_k4s2_whole_supported(side_i, f[i - 1], f[i], self.dt)):
+                pk['w%d' % i] = None    # training step: this layer runs on the whole-sample kernel (image 'ww' below)
             else:
                 pk['w%d' % i] = self._empty(8, f[i], 8 * f[i - 1], dtype=torch.uint8 if q else None)
                 L.call('vv_pack_convT_k4s2', L.ptr(wk), L.ptr(pk['w%d' % i]), f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
@@ -425,9 +428,11 @@ class DecoderEngine(_EngineBase):
                 if pk['scale%d' % i] is not None:
                     pk['scale%d' % i].mul_(qs)
             elif direct:
-                pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
-                L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
-                if not os.environ.get('VV_NO_WHOLE') and L.load().vv_convT3d_k4s2_whole_supported(side_i, f[i - 1], f[i], self.dt):
+                whole = not os.environ.get('VV_NO_WHOLE') and bool(L.load().vv_convT3d_k4s2_whole_supported(side_i, f[i - 1], f[i], self.dt))
+                if not (whole and not self._want_fold):       # (the training step runs the whole-sample kernel: no fragment image)
+                    pk['wf%d' % i] = self._empty(64 * f[i - 1] * f[i])
+                    L.call('vv_pack_convT_k4s2_frag', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['wf%d' % i]), f[i - 1], f[i], st)
+                if whole:
                     # the 8^3 x 128 -> 16^3 x 64 layer of the 32^3 model: one whole sample resident in LDS per workgroup
                     pk['ww%d' % i] = self._empty(64 * f[i - 1] * f[i])
                     L.call('vv_pack_convT_k4s2_skip', L.ptr(p['convT%d/kernel' % i]), L.ptr(pk['ww%d' % i]), f[i - 1], f[i], st)

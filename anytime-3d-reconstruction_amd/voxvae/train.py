@@ -292,7 +292,7 @@ class Trainer:
             L.call('vv_conv3d_k4s2_fwd', L.ptr(x), L.ptr(wp), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
         return y
 
-    def _convT(self, x, w_keras, B, side, cin, cout, packed=None, packed_frag=None):
+    def _convT(self, x, w_keras, B, side, cin, cout, packed=None, packed_frag=None, packed_whole=None):
         """Conv3DTranspose k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cout,cin]: the forward
         transposed layers (packed / packed_frag = the engine's images) and the data gradients of the strided convolutions."""
         dt, st = self.dt, _st()
@@ -311,8 +311,10 @@ class Trainer:
                 and not os.environ.get('VV_NO_WHOLE')):
             # 8^3 x 128 -> 16^3 x 64 (the widest decoder layer forward, and the data gradient of the widest encoder layer):
             # whole-sample kernel; its weight image is packed here (the weights change every step)
-            wk = self._aempty(64 * cin * cout)
-            L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wk), cin, cout, st)
+            wk = packed_whole                        # the forward layer: the engine's image; a data gradient packs its own
+            if wk is None:
+                wk = self._aempty(64 * cin * cout)
+                L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wk), cin, cout, st)
             L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(x), L.ptr(wk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, st)
         elif L.load().vv_convT3d_k4s2_direct_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT'):
             wf = packed_frag
@@ -475,7 +477,7 @@ class Trainer:
         side = S
         for i in range(1, len(fd) - 1):
             c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i], packed=dec.packed['w%d' % i],
-                            packed_frag=dec.packed.get('wf%d' % i))
+                            packed_frag=dec.packed.get('wf%d' % i), packed_whole=dec.packed.get('ww%d' % i))
             side *= 2
             h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
             dc_.append(c); dh_.append(h); dbn.append(bn)
