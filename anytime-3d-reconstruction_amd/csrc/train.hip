@@ -1025,7 +1025,9 @@ int launch_wgrad(const WgradArgs &a, const WgradPlan &p, float *out, float alpha
 }
 
 template <int AMODE>
-int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipStream_t st) {
+int launch_wgrad_bf16(const WgradBArgs &a_in, const WgradPlan &p, float *out, hipStream_t st) {
+    WgradBArgs a = a_in;
+    if (p.splits == 1) a.slabs = out;              // one share: its "slab" IS the result (the reduce pass was a 33 MB copy on the 256 <-> 512 layers)
     const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<AMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1035,7 +1037,7 @@ int launch_wgrad_bf16(const WgradBArgs &a, const WgradPlan &p, float *out, hipSt
     if (AMODE == 2 && a.N <= 64) VV_LAUNCH((wgrad_bf16_kernel<2, true>), dim3(tiles, p.splits), dim3(256), 32768, st, a);
     else VV_LAUNCH((wgrad_bf16_kernel<AMODE>), dim3(tiles, p.splits), dim3(256), 65536, st, a);
     const long n = (long)a.M * a.N;
-    launch_wgrad_reduce(a.slabs, out, n, p.splits, 1.f, 0, st);
+    if (p.splits > 1) launch_wgrad_reduce(a.slabs, out, n, p.splits, 1.f, 0, st);
     return vv_launch_status();
 }
 }  // namespace
