@@ -81,7 +81,8 @@ __device__ __forceinline__ float bn_act_grad(float u, int act) {                
 
 // Per-block partial sums over a row range.  MODE 0: (sum x, sum x^2).  MODE 1: (sum du, sum du * xhat), du = dy * act'.
 // A thread owns V consecutive channels; 256 / (C / V) rows run in parallel, four rows per thread in flight.
-template <int MODE, typename T>
+template <int MODE, typename T, int ACT = -1>     // ACT >= 0: the activation as a compile-time constant (the backward reduction is VALU-bound:
+                                                  // 3.9 TB/s with the run-time switch per element against 5-6 TB/s for its sibling sweeps)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x, const T *__restrict__ dy,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T *__restrict__ x,
                 s0[e] += v[e];
                 s1[e] += v[e] * v[e];
             } else {
-                const float d = g[e] * bn_act_grad<T>(v[e] * sc[e] + sh[e], act);
+                const float d = g[e] * bn_act_grad<T>(v[e] * sc[e] + sh[e], ACT >= 0 ? ACT : act);
                 s0[e] += d;
                 s1[e] += d * ((v[e] - mu[e]) * rs[e]);
             }
@@ -952,7 +953,8 @@ VV_EXPORT int vv_bn_act_bwd(const void *x, const void *dy, const float *scale, c
     const int sweep = bn_sweep_blocks(rows, channels, dtype == VV_BF16 ? 8 : 4);
     if (dtype == VV_BF16) {
         const __bf16 *xb = reinterpret_cast<const __bf16 *>(x), *dyb = reinterpret_cast<const __bf16 *>(dy);
-        VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
+        if (act == VV_ACT_ELU) VV_LAUNCH((bn_reduce_kernel<1, __bf16, VV_ACT_ELU>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
+        else VV_LAUNCH((bn_reduce_kernel<1, __bf16>), dim3(nb), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, part, rows, channels, rpb, act);
         VV_LAUNCH(bn_bwd_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, st, part, nb, channels, dgamma, dbeta);
         VV_LAUNCH(bn_act_bwd_kernel<__bf16>, dim3(sweep), dim3(256), 0, st, xb, dyb, scale, shift, mean, rstd, dgamma, dbeta,
                   reinterpret_cast<__bf16 *>(dx), rows, channels, 1.0f / (float)rows, act);
