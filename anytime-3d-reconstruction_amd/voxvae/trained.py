@@ -23,7 +23,7 @@ from . import synthetic as syn
 
 
 def train_operating_point(voxel=32, latent=64, batch=64, pool=256, lr=1e-3, seed=0, min_iou=0.6, min_abs_logit=17.0,
-                          min_saturated=0.01, check_every=100, max_steps=3000, device='cuda:0', dtype='f32', verbose=False):
+                          min_saturated=0.01, check_every=100, max_steps=3000, device='cuda:0', dtype='f32', verbose=False, variational=True):
     """-> (config, encoder params, decoder params, info).  Trains with `dtype` arithmetic ('f32' = the reference's)."""
     import voxvae
     import src.module.nolbo as nolbo
@@ -31,9 +31,10 @@ def train_operating_point(voxel=32, latent=64, batch=64, pool=256, lr=1e-3, seed
     voxvae.set_default_dtype(dtype)
     voxvae.set_default_device(device)
     try:
-        cfg = syn.make_config(voxel, latent, True)
+        cfg = syn.make_config(voxel, latent, variational)
         with contextlib.redirect_stdout(sys.stderr):
-            model = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg, learning_rate=lr)
+            cls = nolbo.nolboSingleObject_modelnet_category_VAE if variational else nolbo.nolboSingleObject_modelnet_category_AE
+            model = cls(nolbo_structure=cfg, learning_rate=lr)
         xs = torch.from_numpy(syn.make_voxels(pool, voxel, seed=4321 + seed)).to(device)
         gen = torch.Generator(device=device)
         gen.manual_seed(1000 + seed)
@@ -45,10 +46,10 @@ def train_operating_point(voxel=32, latent=64, batch=64, pool=256, lr=1e-3, seed
             for _ in range(check_every):
                 x = xs[(step % nb) * batch:(step % nb + 1) * batch]
                 eps = torch.randn(batch, latent, device=device, generator=gen)
-                model.fit((x, x), _eps=eps)
+                model.fit((x, x), _eps=eps) if variational else model.fit((x, x))
                 step += 1
             # evaluation mode (moving statistics), on device: IoU and the logit range
-            _, z_act, _ = model._encode_latent(probe, probe_eps)
+            _, z_act, _ = model._encode_latent(probe, probe_eps if variational else None)
             _, logits, stats = model._dec_eng.forward(z_act, probe, want_logits=True)
             s = stats.double()
             iou = float((s[:, 1] / torch.clamp(s[:, 1] + s[:, 2] + s[:, 3], min=1.0)).mean())

@@ -200,3 +200,45 @@ def test_config5_geometry_iou_on_trained_weights(trained64, dtype, monkeypatch):
     print('\n[trained 64^3 %s] IoU ref %.4f, delta %.2e, max per-sample delta %.2e' % (dtype, t['iou'].mean(), d_mean, d_max))
     assert d_mean <= gate, (dtype, d_mean)
     assert d_max <= 10 * gate, (dtype, d_max)
+
+
+# ---------------------------------------------------------------------------------------------- the autoencoder class (config 1's model)
+def test_autoencoder_class_on_trained_weights():
+    """nolboSingleObject_modelnet_category_AE (reference nolbo.py:1206-1385; BASELINE.json configs[0]: test_modelnet_AE.py plumbing)
+    fitted with its own fit() (shape loss only, nolbo.py:1247) and compared at the trained operating point: f32 logits within 1e-3 and
+    occupancy exact outside the guard band, bf16 mean IoU within 1e-3; also at config 1's batch of 4."""
+    import voxvae
+    from oracle import c_oracle as co
+    from voxvae import synthetic as syn
+    from voxvae import trained as tr
+    import src.module.nolbo as nolbo
+    cfg, ep, dp, info = tr.train_operating_point(device=DEV, variational=False)
+    assert info['reached'], info
+    n = 64
+    x = np.concatenate([syn.make_voxels(256, 32, seed=4321)[:48], syn.make_voxels(16, 32, seed=777)], axis=0)
+    ref = co.vae_eval_forward(cfg, ep, dp, x, x, np.zeros((n, 64), np.float32), variational=False)
+    iou_r = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
+    print('\n[trained AE] %d fit steps; oracle IoU %.4f, logits in [%.1f, %.1f]' % (info['steps'], iou_r.mean(), ref['logits'].min(), ref['logits'].max()))
+    assert iou_r.mean() >= 0.5 and np.abs(ref['logits']).max() >= 16.0
+    xd = torch.from_numpy(x).to(DEV)
+    for dtype in ('f32', 'bf16'):
+        voxvae.set_default_dtype(dtype)
+        voxvae.set_default_device(DEV)
+        m = nolbo.nolboSingleObject_modelnet_category_AE(nolbo_structure=cfg)
+        m._encoder.set_weights_dict(ep)
+        m._decoder.set_weights_dict(dp)
+        _, z_act, _ = m._encode_latent(xd)
+        _, logits, stats = m._dec_eng.forward(z_act, xd, want_logits=True)
+        lg, s = logits.cpu().numpy(), stats.double().cpu().numpy()
+        iou = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
+        if dtype == 'f32':
+            assert np.abs(lg - ref['logits']).max() <= 1e-3
+            safe = np.abs(ref['logits']) > 1e-4
+            assert np.array_equal((lg >= 0)[safe], (ref['logits'] >= 0)[safe])
+            # config 1's batch: 4 samples through getEval, the same numbers
+            out = m.getEval(inputs=(x[:4], x[:4], syn.make_onehot(4, 40)), category_vectors=syn.make_category_vectors(40, 64), missing_prob=0.0)
+            np.testing.assert_allclose(np.array(out[0]), ref['probs'][:4], atol=2.5e-4)
+            assert abs(float(out[1]) - ref['bce'][:4].mean()) <= 2e-4 * ref['bce'][:4].mean()
+        else:
+            assert abs(iou.mean() - iou_r.mean()) <= 1e-3 and np.abs(iou - iou_r).max() <= 5e-3
+        print('[trained AE %s] max |dlogit| %.2e, IoU delta %.2e' % (dtype, np.abs(lg - ref['logits']).max(), abs(iou.mean() - iou_r.mean())))
