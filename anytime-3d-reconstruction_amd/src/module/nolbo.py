@@ -183,6 +183,8 @@ class _ModelnetBase(object):
         summation order, so the result is the whole-batch result bit for bit (tests/test_gpu_api.py).  Returns None when the
         batch is too small to split or no pinned block is available (the caller then takes the plain path)."""
         from voxvae import hostio as _H
+        if getattr(self, '_enc_eng', None) is None or input_images.ndim != 5:
+            return None                                  # the image -> 3D model: its inputs are images / head outputs, not voxel grids
         B = int(input_images.shape[0])
         nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2'))
         if nchunk < 2 or B < 64 * nchunk or input_images.dtype != np.float32 or not input_images.flags['C_CONTIGUOUS']:
@@ -461,6 +463,11 @@ class nolboSingleObject_VAE(_ModelnetBase):
         eps = torch.randn(enc_out.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
         z, z_act, kl, _, _ = _E.reparam_kl(enc_out, eps, Lz, self._act_dt)
         return z, z_act, kl
+
+    def _encode_decode_seed(self, x, eps=None):
+        """No voxel encoder here (the latent comes from the 2D encoder / supplied head outputs): the split calls."""
+        z, z_act, kl = self._encode_latent(x, eps)
+        return z, z_act, kl, None
 
     def _dev(self, a):
         if callable(getattr(a, 'numpy', None)) and not isinstance(a, (torch.Tensor, DeviceArray)):

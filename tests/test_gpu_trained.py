@@ -242,3 +242,69 @@ def test_autoencoder_class_on_trained_weights():
         else:
             assert abs(iou.mean() - iou_r.mean()) <= 1e-3 and np.abs(iou - iou_r).max() <= 5e-3
         print('[trained AE %s] max |dlogit| %.2e, IoU delta %.2e' % (dtype, np.abs(lg - ref['logits']).max(), abs(iou.mean() - iou_r.mean())))
+
+
+# ---------------------------------------------------------------------------------------------- config 3: the image -> 3D model's decoder half
+def test_config3_decoder_half_on_trained_weights():
+    """BASELINE.json configs[2] (test_pascal_VAE_dr.py; reference nolbo.py:750-928): latent 16, 64^3 decoder, 12 classes, supplied head
+    outputs [B, 32] in place of the 2D encoder.  The decoder is fitted with the class's own fit() (decoder step on
+    the HIP path, nolbo.py:786-833) on 128 (head output, shape) pairs, then: missing_prob = 0 -- the ORACLE reports IoU >= 0.5 and
+    |logit| >= 16 on the pairs, f32 probabilities within 2.5e-4 and bf16 IoU within 1e-3; missing_prob = 0.9 -- both decoder passes of
+    the masked / corrected evaluation against the composed oracle at the trained weights."""
+    import voxvae
+    from oracle import c_oracle as co
+    from oracle import numpy_oracle as no
+    from voxvae import synthetic as syn
+    import src.module.nolbo as nolbo
+    Lz, C, D, pool, B = 16, 12, 64, 128, 32
+    dec_cfg = syn.make_config(D, Lz, True)['decoder']
+    cfg = {'encoder_backbone': {'name': 'nolbo_backbone', 'z_dim': Lz},
+           'encoder_head': {'name': 'nolbo_head', 'output_dim': 2 * Lz, 'filter_num_list': [], 'filter_size_list': [], 'activation': 'elu'},
+           'decoder': dec_cfg}
+    rng = np.random.default_rng(31)
+    head = np.concatenate([rng.standard_normal((pool, Lz)), np.full((pool, Lz), -6.0)], axis=1).astype(np.float32)   # mean | logVar (std 0.05)
+    ys = syn.make_voxels(pool, D, seed=4400)
+    voxvae.set_default_dtype('bf16')
+    voxvae.set_default_device(DEV)
+    m = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg, learning_rate=1e-3)
+    hd, yd = torch.from_numpy(head).to(DEV), torch.from_numpy(ys).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for step in range(600):
+        lo = (step % (pool // B)) * B
+        m.fit((hd[lo:lo + B], yd[lo:lo + B]), _eps=torch.randn(B, Lz, device=DEV, generator=gen))
+    dp = m._decoder.get_weights_dict()
+    n = 16
+    hx, y = head[:n], ys[:n]
+    eps, eps2 = syn.make_eps(n, Lz, seed=71), syn.make_eps(n, Lz, seed=72)
+    mask = syn.make_mask(n, Lz, 0.9, seed=73)
+    oh = syn.make_onehot(n, C, seed=74)
+    cats = head[:C, :Lz].copy()                                   # the prototypes: latent means of 12 training pairs
+    mu, lv = no.split_mean_logvar(hx.astype(np.float64), Lz)
+    z0 = no.sampling(mu, lv, eps)
+    ref0 = co.sigmoid_bce_counts(co.decoder3D_logits(dec_cfg, dp, z0.astype(np.float32)), y)
+    iou0 = ref0[2] / np.maximum(ref0[2] + ref0[3] + ref0[4], 1)
+    lg0 = co.decoder3D_logits(dec_cfg, dp, z0.astype(np.float32))
+    print('\n[trained config 3] oracle IoU %.4f, logits in [%.1f, %.1f]' % (iou0.mean(), lg0.min(), lg0.max()))
+    assert iou0.mean() >= 0.5 and np.abs(lg0).max() >= 16.0
+    zm = z0 * mask
+    zm = np.where(zm == 0, cats.astype(np.float64).mean(0)[None, :] * np.ones_like(zm), zm)
+    idx, _ = no._nearest_category_acc(zm, cats.astype(np.float64), oh, mask=mask.astype(np.float64))
+    zc = np.where(mask == 0, cats[idx].astype(np.float64) + eps2, zm)
+    refs = [co.sigmoid_bce_counts(co.decoder3D_logits(dec_cfg, dp, zz.astype(np.float32)), y) for zz in (zm, zc)]
+    for dtype in ('f32', 'bf16'):
+        voxvae.set_default_dtype(dtype)
+        mm = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg)
+        mm._decoder.set_weights_dict(dp)
+        o0 = mm.getEval(inputs=(hx, y, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+        o9 = mm.getEval(inputs=(hx, y, oh), category_vectors=cats, missing_prob=0.9, _eps=eps, _mask=mask, _eps2=eps2)
+        np.testing.assert_allclose(np.array(mm._z_category_corrected), zc, atol=2e-5)
+        for pred, ref in ((np.array(o0[0]), ref0), (np.array(o9[0]), refs[0]), (np.array(o9[5]), refs[1])):
+            if dtype == 'f32':
+                np.testing.assert_allclose(pred, ref[0], atol=2.5e-4)
+            yh, yt = pred.reshape(n, -1) >= 0.5, y.reshape(n, -1) > 0.5
+            iou = (yh & yt).sum(1) / np.maximum((yh | yt).sum(1), 1)
+            iou_r = ref[2] / np.maximum(ref[2] + ref[3] + ref[4], 1)
+            assert abs(iou.mean() - iou_r.mean()) <= 1e-3, (dtype, abs(iou.mean() - iou_r.mean()))
+        if dtype == 'f32':
+            for got, ref in ((o0[1], ref0), (o9[1], refs[0]), (o9[6], refs[1])):
+                assert abs(float(got) - ref[1].mean()) <= 2e-4 * ref[1].mean()
