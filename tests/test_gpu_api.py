@@ -214,6 +214,14 @@ def test_entry_scripts_run_on_synthetic_data(tmp_path):
     assert l8.shape == (8,) and np.all(np.isfinite(l8))
     l8d = te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2, device_data=True)
     assert l8d.shape == (8,) and np.all(np.isfinite(l8d))
+    # --dump-dir: the three arrays the reference collects per batch and saves at the end of the epoch (test_modelnet_VAE.py:128-130,
+    # 159-165) -- the input of the notebooks' precision / recall tool -- from the host loader and from the device-resident one
+    for dd, dev_data in (('dump_host', False), ('dump_dev', True)):
+        te.train(config=cfg, dataset_path='synthetic:12:16', load_path=str(tmp_path), missing_pr=0.5, batch_size=4, max_iter=2,
+                 device_data=dev_data, dump_dir=str(tmp_path / dd))
+        lab, gt, pr = (np.load(tmp_path / dd / ('0.5' + sfx)) for sfx in ('_cl_label.npy', '_gt.npy', '_pred.npy'))
+        assert lab.shape == (8, 40) and gt.shape == (8, 16, 16, 16, 1) and pr.shape == gt.shape
+        assert set(np.unique(gt)) <= {0.0, 1.0} and pr.min() >= 0 and pr.max() <= 1 and np.all(lab.sum(1) == 1)
     # latent-dropout training (the _dr scripts) and the (D*D, D) text dumps of test_modelnet_3D.py
     res = tr.train(training_epoch=1, learning_rate=1e-3, batch_size=4, config=cfg, dataset_path='synthetic:16:16', max_iter=2, dropout=True)
     assert np.all(np.isfinite(res[0]))
@@ -642,6 +650,17 @@ def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
     np.testing.assert_allclose(float(o2[1]), float(r2[1]), rtol=1e-6)
     small = m.getEval(inputs=(x[:8], x[:8], oh[:8]), category_vectors=cats, missing_prob=0.0, _eps=eps[:8])
     assert not isinstance(small[0], hostio.HostPrediction)
+    # the autoencoder class (no sampling step) takes the same pipeline
+    cfg_ae = syn.make_config(32, 64, False)
+    ma = nolbo.nolboSingleObject_modelnet_category_AE(nolbo_structure=cfg_ae)
+    ma._encoder.set_weights_dict(syn.make_encoder_params(cfg_ae['encoder']))
+    ma._decoder.set_weights_dict(syn.make_decoder_params(cfg_ae['decoder']))
+    oa = ma.getEval(inputs=(x[:128], x[:128], oh[:128]), category_vectors=cats, missing_prob=0.0)
+    ra = ma.getEval(inputs=(xd[:128], xd[:128], oh[:128]), category_vectors=cats, missing_prob=0.0)
+    assert isinstance(oa[0], hostio.HostPrediction)
+    np.testing.assert_array_equal(np.array(oa[0]), np.array(ra[0]))
+    np.testing.assert_allclose([float(v) for v in oa[1:5]], [float(v) for v in ra[1:5]], rtol=1e-6)
+    del oa, ra, ma
     # recycling: dropping the results returns their pinned blocks; the next call takes one from the pool instead of pinning anew
     del out, pred, o2, small
     gc.collect()
