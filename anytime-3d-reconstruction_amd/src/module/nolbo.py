@@ -469,6 +469,45 @@ class nolboSingleObject_VAE(_ModelnetBase):
         z, z_act, kl = self._encode_latent(x, eps)
         return z, z_act, kl, None
 
+    def _getEval_training_mode(self, inputs, category_vectors, missing_prob, _eps, _mask, _eps2):
+        """getEval(training=True) of the image -> 3D model (reference nolbo.py:856-928 passes `training` to the backbone, the head
+        and the decoder): the 2D encoder runs in training mode (torch modules), the decoder's BatchNorm normalises with batch
+        statistics and moves its moving statistics; no optimisation step."""
+        from voxvae import train as _T
+        if category_vectors is None or len(inputs) != 3:
+            raise ValueError('nolboSingleObject_VAE.getEval takes (images, voxels, one-hot) and category_vectors')
+        if getattr(self, '_fwd_dec', None) is None:
+            self._fwd_dec = _T.Trainer.forward_only(dec=self._dec_eng)
+        input_images, output_images, category_list = inputs
+        y, onehot, cats = self._dev(output_images), self._dev(category_list), self._dev(category_vectors)
+        with torch.no_grad():
+            enc_out = self._dev(self._encoder_2d(input_images, training=True))
+        B, Lz, C = enc_out.shape[0], self._latent_dim, cats.shape[0]
+        eps = torch.randn(B, Lz, dtype=torch.float32, device=self._device) if _eps is None else self._dev(_eps)
+        z, _, _, _, _ = _E.reparam_kl(enc_out.contiguous(), eps, Lz, _L.VV_F32)
+        mask = None
+        if missing_prob > 0:
+            if _mask is None:
+                _mask = np.reshape(np.random.choice(2, B * Lz, p=[missing_prob, 1. - missing_prob]), [B, Lz]).astype('float32')
+            mask = self._dev(_mask)
+            zf = torch.empty_like(z)
+            _L.call('vv_latent_mask_fill', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), C, _L.ptr(zf), None, _L.VV_F32, B, Lz, _st())
+            z = zf
+        _, acc = self._category_acc(z, cats, onehot)
+        probs, _, m = self._fwd_dec.decoder_training_mode(z, y)
+        self._z_category = DeviceArray(z)
+        res = (DeviceArray(probs), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]))
+        if missing_prob == 0.0:
+            return res + (0, 0, 0, 0, 0)
+        idx, _ = self._category_acc(z, cats, None, mask)
+        eps2 = torch.randn(B, Lz, dtype=torch.float32, device=self._device) if _eps2 is None else self._dev(_eps2)
+        zc = torch.empty_like(z)
+        _L.call('vv_latent_correct', _L.ptr(z), _L.ptr(mask), _L.ptr(cats), _L.ptr(idx), _L.ptr(eps2), _L.ptr(zc), None, _L.VV_F32, B, Lz, _st())
+        _, acc_c = self._category_acc(zc, cats, onehot)
+        probs_c, _, mc = self._fwd_dec.decoder_training_mode(zc, y)
+        self._z_category_corrected = DeviceArray(zc)
+        return res + (DeviceArray(probs_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
+
     def _dev(self, a):
         if callable(getattr(a, 'numpy', None)) and not isinstance(a, (torch.Tensor, DeviceArray)):
             a = a.numpy()

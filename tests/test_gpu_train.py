@@ -555,3 +555,42 @@ def test_weight_gradient_kernels_at_batch_256_against_float64():
 def ctypes_stream():
     import ctypes
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_image_to_3d_model_getEval_training_true():
+    """nolboSingleObject_VAE.getEval(training=True) (reference nolbo.py:856-928): with supplied head outputs the decoder half runs in
+    training mode -- batch-statistics BatchNorm against the float64 training oracle's decoder forward, moving statistics moved,
+    weights untouched; the masked / corrected form runs both decoder passes in that mode."""
+    import voxvae
+    from oracle import torch_oracle as to
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype('f32')
+    voxvae.set_default_device(DEV)
+    import src.module.nolbo as nolbo
+    D, Lz, B, C = 16, 64, 6, 12
+    cfgv = syn.make_config(D, Lz, True)
+    ep = syn.make_encoder_params(cfgv['encoder'], seed=42, nontrivial_affine=True)
+    dp = syn.make_decoder_params(cfgv['decoder'], seed=43, nontrivial_affine=True, final_gain=2.0)
+    x, eps = syn.make_voxels(B, D, seed=102), syn.make_eps(B, Lz, seed=202)
+    ref = to.fit_step(cfgv, ep, dp, x, x, eps, lr=1e-3, variational=True)      # its encoder output = the "head output" fed below
+    cfg = {'encoder_backbone': {'name': 'nolbo_backbone', 'z_dim': Lz},
+           'encoder_head': {'name': 'nolbo_head', 'output_dim': 2 * Lz, 'filter_num_list': [], 'filter_size_list': [], 'activation': 'elu'},
+           'decoder': cfgv['decoder']}
+    m = nolbo.nolboSingleObject_VAE(nolbo_structure=cfg)
+    m._decoder.set_weights_dict(dp)
+    oh, cats = syn.make_onehot(B, C), syn.make_category_vectors(C, Lz)
+    head = ref['enc_out'].astype(np.float32)
+    out = m.getEval(inputs=(head, x, oh), category_vectors=cats, training=True, missing_prob=0.0, _eps=eps)
+    assert len(out) == 10 and out[5:] == (0, 0, 0, 0, 0)
+    np.testing.assert_allclose(np.array(out[0]), ref['probs'], rtol=0, atol=2e-5)
+    assert abs(float(out[1]) - ref['loss_shape']) <= 2e-4 * abs(ref['loss_shape'])
+    new_d = m._decoder.get_weights_dict()
+    for k, v in new_d.items():
+        if k.endswith(('moving_mean', 'moving_variance')):
+            np.testing.assert_allclose(v, ref['params']['dec/' + k], rtol=1e-4, atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_array_equal(v, dp[k], err_msg=k)
+    mask = (np.random.default_rng(1).random((B, Lz)) >= 0.5).astype(np.float32)
+    o2 = m.getEval(inputs=(head, x, oh), category_vectors=cats, training=True, missing_prob=0.5, _eps=eps, _mask=mask, _eps2=syn.make_eps(B, Lz, seed=5))
+    assert len(o2) == 10 and all(np.isfinite(float(v)) for v in o2[1:5] + o2[6:10])
+    assert np.abs(np.array(o2[0]) - np.array(o2[5])).max() > 1e-3
