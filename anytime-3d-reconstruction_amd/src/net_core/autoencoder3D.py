@@ -183,8 +183,20 @@ class Model(object):
             os.makedirs(d, exist_ok=True)
         np.savez(path + _WEIGHT_SUFFIX, **{k.replace('/', '.'): v for k, v in self._engine.get_params().items()})
 
+    def save_tf_checkpoint(self, path):
+        """`<path>.index` + `<path>.data-00000-of-00001` with Keras' object-graph keys (voxvae/tf_checkpoint.py)."""
+        from voxvae import tf_checkpoint
+        p = self._engine.get_params()
+        tf_checkpoint.save_keras_checkpoint(path, {k: p[k] for k in self._engine.param_shapes()})
+
     def load_weights(self, path):
+        """<path>.voxvae.npz (this repo's save_weights) or, when only `<path>.index` exists, a TensorFlow checkpoint written
+        by the reference's `save_weights(path)` (nolbo.py:1568-1574), read by voxvae/tf_checkpoint.py."""
         f = path if path.endswith(_WEIGHT_SUFFIX) else path + _WEIGHT_SUFFIX
+        if not os.path.exists(f) and os.path.exists(path + '.index'):
+            from voxvae import tf_checkpoint
+            self._engine.set_params(tf_checkpoint.load_keras_checkpoint(path, self._engine.param_shapes()))
+            return
         with np.load(f) as z:
             params = {k.replace('.', '/'): z[k] for k in z.files}
         missing = set(self._engine.param_shapes()) - set(params)

@@ -154,6 +154,16 @@ def test_builders_and_checkpoints(tmp_path):
     b = m2.getEval(inputs=(x, x), _eps=eps)
     assert np.array_equal(np.array(a[0]), np.array(b[0]))
     m2.loadDecoder(str(tmp_path), file_name='decoder')                        # train_modelnet_category_VAE.py:46-52
+    # a directory holding TensorFlow-format checkpoints (what the reference's saveModel writes, nolbo.py:1568-1574): loadModel reads
+    # `<name>.index` + `<name>.data-*` when no .voxvae.npz is there (voxvae/tf_checkpoint.py; format self-written, see its header)
+    tfdir = tmp_path / 'tf'
+    m1._encoder.save_tf_checkpoint(str(tfdir / 'encoder3D'))
+    m1._decoder.save_tf_checkpoint(str(tfdir / 'decoder'))
+    assert os.path.exists(tfdir / 'encoder3D.index') and os.path.exists(tfdir / 'decoder.data-00000-of-00001')
+    m3 = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m3.loadModel(str(tfdir))
+    c = m3.getEval(inputs=(x, x), _eps=eps)
+    assert np.array_equal(np.array(a[0]), np.array(c[0]))
 
 
 def test_function_module_ops():

@@ -244,3 +244,63 @@ def test_bench_refuses_more_gpus_than_visible():
     assert p.returncode != 0
     assert '2 GPUs requested, %d visible' % torch.cuda.device_count() in (p.stderr + p.stdout)
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+
+
+# ------------------------------------------------------------------------------------------------ TensorFlow checkpoint files
+def test_tf_checkpoint_crc32c_known_answers_and_table_round_trip(tmp_path):
+    """voxvae/tf_checkpoint.py: CRC32C against RFC 3720's vectors, LevelDB's mask, and a multi-block index round trip."""
+    from voxvae import tf_checkpoint as tc
+    assert tc.crc32c(b'123456789') == 0xE3069283
+    assert tc.crc32c(bytes(32)) == 0x8A9136AA and tc.crc32c(b'\xff' * 32) == 0x62A8AB43
+    assert tc.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tc.crc32c(b'world', tc.crc32c(b'hello ')) == tc.crc32c(b'hello world')
+    assert tc._mask(0) == 0xa282ead8                             # rotate right 15, add kMaskDelta
+    rng = np.random.default_rng(0)
+    names = ['conv%d/%s' % (i, leaf) for i in range(40) for leaf in ('kernel', 'bias')]
+    names += ['bn%d/%s' % (i, leaf) for i in range(40) for leaf in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+    tensors = {'layer_with_weights-%d/%s/.ATTRIBUTES/VARIABLE_VALUE' % (i, n): rng.standard_normal((3, i % 5 + 1, 2)).astype(np.float32)
+               for i, n in enumerate(names)}
+    tensors['save_counter/.ATTRIBUTES/VARIABLE_VALUE'] = np.array(7, dtype=np.int64)
+    prefix = str(tmp_path / 'ck' / 'encoder')
+    tc.write_checkpoint(prefix, tensors, block_bytes=512)         # many data blocks: exercises the index block and key prefixes
+    keys = [k for k, _ in tc.read_index(prefix + '.index')]
+    assert keys[0] == b'' and keys[1:] == sorted(k.encode() for k in tensors)
+    back = tc.read_checkpoint(prefix)
+    assert set(back) == set(tensors)
+    for k in tensors:
+        assert back[k].dtype == tensors[k].dtype and back[k].shape == tensors[k].shape and np.array_equal(back[k], tensors[k])
+    # a flipped byte inside a block is caught by the block CRC; a foreign file by the magic
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[20] ^= 0x40
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='CRC'):
+        tc.read_checkpoint(prefix)
+    open(prefix + '.index', 'wb').write(b'not a table' * 10)
+    with pytest.raises(ValueError, match='magic'):
+        tc.read_checkpoint(prefix)
+
+
+def test_tf_checkpoint_keras_object_graph_keys_follow_creation_order(tmp_path):
+    """`layer_with_weights-<i>` counts the layers that own variables in creation order (autoencoder3D.py:26-139 creates
+    Conv3D then BatchNormalization per block); shapes are checked, bfloat16 entries widen to float32."""
+    from voxvae import tf_checkpoint as tc
+    shapes = {'conv0/kernel': (4, 4, 4, 1, 8), 'conv0/bias': (8,), 'bn0/gamma': (8,), 'bn0/beta': (8,), 'bn0/moving_mean': (8,),
+              'bn0/moving_variance': (8,), 'dense/kernel': (8, 6), 'dense/bias': (6,)}
+    keys = tc.keras_object_graph_keys(list(shapes))
+    assert keys[0] == ('layer_with_weights-0/kernel/.ATTRIBUTES/VARIABLE_VALUE', 'conv0/kernel')
+    assert keys[2] == ('layer_with_weights-1/gamma/.ATTRIBUTES/VARIABLE_VALUE', 'bn0/gamma')
+    assert keys[-1] == ('layer_with_weights-2/bias/.ATTRIBUTES/VARIABLE_VALUE', 'dense/bias')
+    rng = np.random.default_rng(1)
+    params = {k: rng.standard_normal(s).astype(np.float32) for k, s in shapes.items()}
+    prefix = str(tmp_path / 'enc')
+    tc.save_keras_checkpoint(prefix, params)
+    back = tc.load_keras_checkpoint(prefix, shapes)
+    assert list(back) == list(shapes) and all(np.array_equal(back[k], params[k]) for k in shapes)
+    with pytest.raises(ValueError, match='shape'):
+        tc.load_keras_checkpoint(prefix, dict(shapes, **{'dense/bias': (7,)}))
+    with pytest.raises(ValueError, match='lacks'):
+        tc.load_keras_checkpoint(prefix, dict(shapes, **{'extra/kernel': (1,)}))
+    # a bfloat16 entry (DT_BFLOAT16 = 14), built by hand: value 1.5 = 0x3FC0
+    entry = tc._entry_proto(14, (2,), 0, 0, 4, 0)
+    e = tc._parse_proto(entry)
+    assert e[1] == [14] and tc._shape_of(e[2][0]) == (2,) and e[5] == [4]
