@@ -262,6 +262,11 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
                  : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])                    \
                  : "n"(N)                                                                                                           \
                  : "memory")
+#define CW16_SB __builtin_amdgcn_sched_barrier(0)
+#define CW16_RD(D, A, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(D) : "v"(A), "n"(OFF) : "memory")
+#define CW16_MF(F, COT, CT)                                                                                                         \
+    acc[COT][CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + COT]),                          \
+                                                           *reinterpret_cast<const bf16x8 *>(&F[CT]), acc[COT][CT], 0, 0, 0)
 #define CW16_MFMA(F)                                                                                                                \
     do {                                                                                                                            \
         _Pragma("unroll") for (int cot = 0; cot < 4; ++cot) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                        \
@@ -383,37 +388,54 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
     for (int pi = 0; pi < npar; ++pi) {
         const int p = p0 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
         const int pn = p + 1, pnd = (pn >> 2) & 1, pnh = (pn >> 1) & 1, pnw = pn & 1;
+        // One chunk = two 32-deep k-steps of 16 MFMAs.  The fragment reads of the NEXT k-step, the chunk's LDS-DMA piece and the
+        // address arithmetic sit in the gaps between this k-step's MFMAs (two per gap), not in a burst ahead of them: with the
+        // burst form both waves of a SIMD left the barrier into ~250 cycles of memory-instruction issue with the matrix pipe idle
+        // (in-kernel stamps, profiles/microbench/mb_ctw_stamp.py: 1869 cycles per chunk against 1024 of MFMA work).
         auto chunk = [&](auto j_c) {
             constexpr int J = decltype(j_c)::value, A = J >> 1, KH = J & 1;
             unsigned xq[4];                          // second 32-deep k-step of this K half: slots +4
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) xq[ct] = ua[ct] ^ (KH ? 192u : 64u);
-            CW16_LD(Q, xq, ws ^ 64u);
-            CW16_WAIT(P, 8);
-            CW16_MFMA(P);
-            if (KH == 0) {
+            const unsigned wq = ws ^ 64u;
+            CW16_WAIT(P, 0);
+            CW16_SB;
+            CW16_MF(P, 0, 0); CW16_MF(P, 0, 1); CW16_SB; CW16_RD(Q[0], xq[0], 0); CW16_RD(Q[4], wq, 0); CW16_SB;
+            CW16_MF(P, 0, 2); CW16_MF(P, 0, 3); CW16_SB; CW16_RD(Q[1], xq[1], 0); CW16_RD(Q[5], wq, 2048); CW16_SB;
+            CW16_MF(P, 1, 0); CW16_MF(P, 1, 1); CW16_SB; CW16_RD(Q[2], xq[2], 0); CW16_RD(Q[6], wq, 4096); CW16_SB;
+            CW16_MF(P, 1, 2); CW16_MF(P, 1, 3); CW16_SB; CW16_RD(Q[3], xq[3], 0); CW16_RD(Q[7], wq, 6144); CW16_SB;
+            CW16_MF(P, 2, 0); CW16_MF(P, 2, 1); CW16_MF(P, 2, 2); CW16_MF(P, 2, 3);
+            if (KH == 0) {                           // next tap's row addresses: VALU in the shadow of the MFMAs around it
                 if (A < 7) tap_setup(std::integral_constant<int, (A + 1) & 7>{}, pd, ph, pw, ub);
                 else tap_setup(std::integral_constant<int, 0>{}, pnd, pnh, pnw, ub);
             }
+            CW16_MF(P, 3, 0); CW16_MF(P, 3, 1); CW16_MF(P, 3, 2); CW16_MF(P, 3, 3);
+            CW16_SB;
             CW16_WAIT(Q, 0);
             if (J < 2 && pi > 0) cw_wait_vm<9>();
             else cw_wait_vm<1>();
             __builtin_amdgcn_s_barrier();
+            CW16_SB;
+            CW16_MF(Q, 0, 0); CW16_MF(Q, 0, 1); CW16_SB;
             issue_w(cw, stg);
             ++cw;
             stg = stg == CW_NST - 1 ? 0 : stg + 1;
             ws = wl + stg * CW_WST;
             if (KH == 0) {
-                unsigned xn[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) xn[ct] = ua[ct] ^ 128u;
-                CW16_LD(P, xn, ws);
+                for (int ct = 0; ct < 4; ++ct) xq[ct] = ua[ct] ^ 128u;
             } else {
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) ua[ct] = ub[ct];
-                CW16_LD(P, ua, ws);
+                for (int ct = 0; ct < 4; ++ct) xq[ct] = ua[ct] = ub[ct];
             }
-            CW16_MFMA(Q);
+            CW16_SB;
+            CW16_MF(Q, 0, 2); CW16_MF(Q, 0, 3); CW16_SB; CW16_RD(P[0], xq[0], 0); CW16_RD(P[4], ws, 0); CW16_SB;
+            CW16_MF(Q, 1, 0); CW16_MF(Q, 1, 1); CW16_SB; CW16_RD(P[1], xq[1], 0); CW16_RD(P[5], ws, 2048); CW16_SB;
+            CW16_MF(Q, 1, 2); CW16_MF(Q, 1, 3); CW16_SB; CW16_RD(P[2], xq[2], 0); CW16_RD(P[6], ws, 4096); CW16_SB;
+            CW16_MF(Q, 2, 0); CW16_MF(Q, 2, 1); CW16_SB; CW16_RD(P[3], xq[3], 0); CW16_RD(P[7], ws, 6144); CW16_SB;
+            CW16_MF(Q, 2, 2); CW16_MF(Q, 2, 3);
+            CW16_MF(Q, 3, 0); CW16_MF(Q, 3, 1); CW16_MF(Q, 3, 2); CW16_MF(Q, 3, 3);
+            CW16_SB;
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
