@@ -342,6 +342,11 @@ __global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__r
                  : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])                    \
                  : "n"(N)                                                                                                           \
                  : "memory")
+#define CD16_SB __builtin_amdgcn_sched_barrier(0)
+#define CD16_RD(D, A, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(D) : "v"(A), "n"(OFF) : "memory")
+#define CD16_MF(F, COT, CT)                                                                                                         \
+    acc[COT][CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + COT]),                          \
+                                                           *reinterpret_cast<const bf16x8 *>(&F[CT]), acc[COT][CT], 0, 0, 0)
 #define CD16_MFMA(F)                                                                                                                \
     do {                                                                                                                            \
         _Pragma("unroll") for (int cot = 0; cot < 4; ++cot) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                        \
@@ -362,18 +367,38 @@ __global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__r
             constexpr int AN = (A + 1) & 7, AWN = AN & 1, TON = (((AN >> 2) & 1) * 81 + ((AN >> 1) & 1) * 9 + AWN) * CD_RB;
             const int c = q * 8 + A;
             const unsigned wsel = (c % CD_NST) * CD_WST, wnext = ((c + 1) % CD_NST) * CD_WST;
-            CD16_LD(Q, xo[AW][1] + tsel, TO, wo[1] + wsel);
-            CD16_WAIT(P, 8);
-            CD16_MFMA(P);
+            // The fragment reads of the next k-step (two per gap), the LDS-DMA pieces and their address arithmetic sit BETWEEN this
+            // k-step's MFMAs, not in a burst ahead of them (convt_whole.hip: both waves of a SIMD leave the barrier in phase, and
+            // a burst of memory instructions there leaves the matrix pipe idle); every LDS wait is lgkmcnt(0) at a point where
+            // the reads have had 6-8 MFMAs to land.
+            const unsigned xq = xo[AW][1] + tsel, wq = wo[1] + wsel;
+            CD16_WAIT(P, 0);
+            CD16_SB;
+            CD16_MF(P, 0, 0); CD16_MF(P, 0, 1); CD16_SB; CD16_RD(Q[0], xq, TO); CD16_RD(Q[4], wq, 0); CD16_SB;
+            CD16_MF(P, 0, 2); CD16_MF(P, 0, 3); CD16_SB; CD16_RD(Q[1], xq, TO + 2304); CD16_RD(Q[5], wq, 2048); CD16_SB;
+            CD16_MF(P, 1, 0); CD16_MF(P, 1, 1); CD16_SB; CD16_RD(Q[2], xq, TO + 4608); CD16_RD(Q[6], wq, 4096); CD16_SB;
+            CD16_MF(P, 1, 2); CD16_MF(P, 1, 3); CD16_SB; CD16_RD(Q[3], xq, TO + 6912); CD16_RD(Q[7], wq, 6144); CD16_SB;
+            CD16_MF(P, 2, 0); CD16_MF(P, 2, 1); CD16_MF(P, 2, 2); CD16_MF(P, 2, 3);
+            CD16_MF(P, 3, 0); CD16_MF(P, 3, 1); CD16_MF(P, 3, 2); CD16_MF(P, 3, 3);
+            CD16_SB;
             CD16_WAIT(Q, 0);                       // every LDS read of chunk c has returned: its stage may be refilled
             // chunk c+1's weights (and, before tap 0 of the next phase, the whole next tile) have landed.  Pieces issued
             // after w(c+1): [x piece of tap A-1] w(c+2) x2; tap 7 needs the x piece of tap 6, which precedes w(c+2).
             wait_vm<(A == 0 || A == 7) ? 2 : 3>();
             __syncthreads();
-            if (A < 7) issue_x(q + 1, A);
+            CD16_SB;
+            CD16_MF(Q, 0, 0); CD16_MF(Q, 0, 1);
+            if (A < 7) issue_x(q + 1, A);          // (the address arithmetic of the pieces: VALU beside the MFMAs around it)
+            CD16_MF(Q, 0, 2); CD16_MF(Q, 0, 3);
             issue_w(c + 3);
-            CD16_LD(P, xo[AWN][0] + (A == 7 ? tnext : tsel), TON, wo[0] + wnext);
-            CD16_MFMA(Q);
+            const unsigned xp = xo[AWN][0] + (A == 7 ? tnext : tsel), wp = wo[0] + wnext;
+            CD16_SB;
+            CD16_MF(Q, 1, 0); CD16_MF(Q, 1, 1); CD16_SB; CD16_RD(P[0], xp, TON); CD16_RD(P[4], wp, 0); CD16_SB;
+            CD16_MF(Q, 1, 2); CD16_MF(Q, 1, 3); CD16_SB; CD16_RD(P[1], xp, TON + 2304); CD16_RD(P[5], wp, 2048); CD16_SB;
+            CD16_MF(Q, 2, 0); CD16_MF(Q, 2, 1); CD16_SB; CD16_RD(P[2], xp, TON + 4608); CD16_RD(P[6], wp, 4096); CD16_SB;
+            CD16_MF(Q, 2, 2); CD16_MF(Q, 2, 3); CD16_SB; CD16_RD(P[3], xp, TON + 6912); CD16_RD(P[7], wp, 6144); CD16_SB;
+            CD16_MF(Q, 3, 0); CD16_MF(Q, 3, 1); CD16_MF(Q, 3, 2); CD16_MF(Q, 3, 3);
+            CD16_SB;
         };
         tap(std::integral_constant<int, 0>{});
         tap(std::integral_constant<int, 1>{});
