@@ -236,18 +236,27 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mma16 = [&](const sd_u4 *xf, const sd_u4 *wf, int nt0, int vmask) {
+    auto mma4 = [&](const sd_u4 *xf, const sd_u4 *wf, int nt0, int vmask, auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        if (vmask & (1 << i)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (vmask & (1 << i)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[j]),
-                                                                               *reinterpret_cast<const bf16x8 *>(&xf[i]),
-                                                                               acc[i][nt0 + j], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j)
+                acc[i][nt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[j]),
+                                                                           *reinterpret_cast<const bf16x8 *>(&xf[i]), acc[i][nt0 + j], 0, 0, 0);
         }
     };
+    // A block of 16 MFMAs with the fragment reads of a later block between its cell tiles (and R0 ahead of nothing: the first tile's
+    // MFMAs go first): the memory instructions of a block sit in the gaps of the previous one instead of in a burst between two
+    // blocks, where both waves of a SIMD would issue them in phase with the matrix pipe idle (convt_whole.hip, in-kernel stamps).
+#define SD_MMA_RD(XF, WF, NT0, VM, R1, R2)                                                                                  \
+    do {                                                                                                                    \
+        mma4(XF, WF, NT0, VM, std::integral_constant<int, 0>{});                                                            \
+        R1;                                                                                                                 \
+        mma4(XF, WF, NT0, VM, std::integral_constant<int, 1>{});                                                            \
+        R2;                                                                                                                 \
+        mma4(XF, WF, NT0, VM, std::integral_constant<int, 2>{});                                                            \
+        mma4(XF, WF, NT0, VM, std::integral_constant<int, 3>{});                                                            \
+    } while (0)
     // tiles whose cell index i + off stays inside 0..3, as a 4-bit mask over the wave's tiles
     auto tile_mask = [&](const int *cell, int off) -> int {
         int m = 0;
@@ -304,6 +313,17 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
         else { SD_RD(XF[0], xb0[0], XO); SD_RD(XF[1], xb0[1], XO); SD_RD(XF[2], xb0[2], XO); SD_RD(XF[3], xb0[3], XO); }     \
         SD_RD(WF[0], wbc, WO); SD_RD(WF[1], wbc, WO + 2048); SD_RD(WF[2], wbc, WO + 4096); SD_RD(WF[3], wbc, WO + 6144);    \
     } while (0)
+#define SD_CONV_RDX(AD, J, XF)                                                                                              \
+    do {                                                                                                                    \
+        constexpr int XO = (AD) * 2048 + ((J) >> 1) * 512;                                                                  \
+        if ((J) & 1) { SD_RD(XF[0], xb1[0], XO); SD_RD(XF[1], xb1[1], XO); SD_RD(XF[2], xb1[2], XO); SD_RD(XF[3], xb1[3], XO); } \
+        else { SD_RD(XF[0], xb0[0], XO); SD_RD(XF[1], xb0[1], XO); SD_RD(XF[2], xb0[2], XO); SD_RD(XF[3], xb0[3], XO); }     \
+    } while (0)
+#define SD_CONV_RDW(AD, J, WF)                                                                                              \
+    do {                                                                                                                    \
+        constexpr int WO = (AD) * SD_WST + (J) * 8192;                                                                      \
+        SD_RD(WF[0], wbc, WO); SD_RD(WF[1], wbc, WO + 2048); SD_RD(WF[2], wbc, WO + 4096); SD_RD(WF[3], wbc, WO + 6144);    \
+    } while (0)
         setup(0, 0);
         SD_CONV_RD(0, 0, xP, wP);
         int qa = 0, ca = 0;                             // (q, c) of tile T, T + 1, T + 2
@@ -314,45 +334,40 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
             // ---- unit AD = 0
             {
                 const int u = 2 * T;
-                SD_CONV_RD(0, 1, xQ, wQ);
-                SD_WAIT8(8, xP, wP);
-                mma16(xP, wP, 0, dm0 & hm0);
-                SD_CONV_RD(0, 2, xP, wP);
-                SD_WAIT8(8, xQ, wQ);
-                mma16(xQ, wQ, 0, dm0 & hm0);
-                SD_CONV_RD(0, 3, xQ, wQ);
-                SD_WAIT8(8, xP, wP);
-                mma16(xP, wP, 0, dm0 & hm1);
+                SD_WAIT8(0, xP, wP);
+                SD_MMA_RD(xP, wP, 0, dm0 & hm0, SD_CONV_RDX(0, 1, xQ), SD_CONV_RDW(0, 1, wQ));
+                SD_WAIT8(0, xQ, wQ);
+                SD_MMA_RD(xQ, wQ, 0, dm0 & hm0, SD_CONV_RDX(0, 2, xP), SD_CONV_RDW(0, 2, wP));
+                SD_WAIT8(0, xP, wP);
+                SD_MMA_RD(xP, wP, 0, dm0 & hm1, SD_CONV_RDX(0, 3, xQ), SD_CONV_RDW(0, 3, wQ));
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (u + 2 < nunits) issue_w(u + 2, qb, cb);
-                SD_CONV_RD(1, 0, xP, wP);
-                mma16(xQ, wQ, 0, dm0 & hm1);
+                SD_MMA_RD(xQ, wQ, 0, dm0 & hm1, if (u + 2 < nunits) issue_w(u + 2, qb, cb); SD_CONV_RDX(1, 0, xP), SD_CONV_RDW(1, 0, wP));
             }
             // ---- unit AD = 1
             {
                 const int u = 2 * T + 1;
-                SD_CONV_RD(1, 1, xQ, wQ);
-                SD_WAIT8(8, xP, wP);
-                mma16(xP, wP, 0, dm1 & hm0);
-                SD_CONV_RD(1, 2, xP, wP);
-                SD_WAIT8(8, xQ, wQ);
-                mma16(xQ, wQ, 0, dm1 & hm0);
-                SD_CONV_RD(1, 3, xQ, wQ);
-                SD_WAIT8(8, xP, wP);
-                mma16(xP, wP, 0, dm1 & hm1);
+                SD_WAIT8(0, xP, wP);
+                SD_MMA_RD(xP, wP, 0, dm1 & hm0, SD_CONV_RDX(1, 1, xQ), SD_CONV_RDW(1, 1, wQ));
+                SD_WAIT8(0, xQ, wQ);
+                SD_MMA_RD(xQ, wQ, 0, dm1 & hm0, SD_CONV_RDX(1, 2, xP), SD_CONV_RDW(1, 2, wP));
+                SD_WAIT8(0, xP, wP);
+                SD_MMA_RD(xP, wP, 0, dm1 & hm1, SD_CONV_RDX(1, 3, xQ), SD_CONV_RDW(1, 3, wQ));
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                const int lastmask = dm1 & hm1;
+                mma4(xQ, wQ, 0, lastmask, std::integral_constant<int, 0>{});
                 if (u + 2 < nunits) issue_w(u + 2, qb, cb);
                 if (T + 2 < ntiles) issue_a(T + 2, qc, cc);
-                const int lastmask = dm1 & hm1;
+                mma4(xQ, wQ, 0, lastmask, std::integral_constant<int, 1>{});
                 if (T + 1 < ntiles) {
                     setup(T + 1, qb);
                     SD_CONV_RD(0, 0, xP, wP);
                 }
-                mma16(xQ, wQ, 0, lastmask);
+                mma4(xQ, wQ, 0, lastmask, std::integral_constant<int, 2>{});
+                mma4(xQ, wQ, 0, lastmask, std::integral_constant<int, 3>{});
             }
             qa = qb; ca = cb; qb = qc; cb = cc;
             qc = cb + 1 < NC ? qb : qb + 1; cc = cb + 1 < NC ? cb + 1 : 0;
@@ -366,6 +381,8 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #undef SD_CONV_RD
+#undef SD_CONV_RDX
+#undef SD_CONV_RDW
     } else {
         // tap (ad, ah, aw) of parity (pd, ph, hv) reads cell (d + pd - ad, h + ph - ah, w + hv - aw)
         const int jw0 = lw + hv, jw1 = lw + hv - 1;        // aw = 0 / 1
@@ -409,29 +426,31 @@ __global__ __launch_bounds__(512, 1) void sd_kernel(const SdArgs a) {
                 constexpr int AD = (A >> 2) & 1, AH = (A >> 1) & 1, AN = (A + 1) & 7;
                 const int u = 8 * T + A;
                 const int vm = dmA[AD] & hmA[AH];
-                SD_T_W(A, wbt0, 1, wQ);
-                SD_WAIT8(4, xP, wP);
-                mma16(xP, wP, 0, vm);
-                SD_T_X(A, 1, xQ); SD_T_W(A, wbt1, 0, wP);
-                SD_WAIT8(8, xP, wQ);
-                mma16(xP, wQ, 4, vm);
-                SD_T_W(A, wbt1, 1, wQ);
-                SD_WAIT8(4, xQ, wP);
-                mma16(xQ, wP, 0, vm);
+                SD_WAIT8(0, xP, wP);
+                SD_MMA_RD(xP, wP, 0, vm, SD_T_W(A, wbt0, 1, wQ), (void)0);
+                SD_WAIT8(0, xP, wQ);
+                SD_MMA_RD(xP, wQ, 4, vm, SD_T_X(A, 1, xQ), SD_T_W(A, wbt1, 0, wP));
+                SD_WAIT8(0, xQ, wP);
+                SD_MMA_RD(xQ, wP, 0, vm, SD_T_W(A, wbt1, 1, wQ), (void)0);
                 SD_WAIT8(0, xQ, wQ);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                mma4(xQ, wQ, 4, vm, std::integral_constant<int, 0>{});
                 if (u + 2 < nunits) issue_w(u + 2, 0, 0);
                 if (A == 7) {
                     if (T + 2 < ntiles) issue_a(T + 2, 0, 0);
+                    mma4(xQ, wQ, 4, vm, std::integral_constant<int, 1>{});
                     if (T + 1 < ntiles) {
                         setup(T + 1);
                         SD_T_X(AN, 0, xP); SD_T_W(AN, wbt0, 0, wP);
                     }
                 } else {
-                    SD_T_X(AN, 0, xP); SD_T_W(AN, wbt0, 0, wP);
+                    SD_T_X(AN, 0, xP);
+                    mma4(xQ, wQ, 4, vm, std::integral_constant<int, 1>{});
+                    SD_T_W(AN, wbt0, 0, wP);
                 }
-                mma16(xQ, wQ, 4, vm);
+                mma4(xQ, wQ, 4, vm, std::integral_constant<int, 2>{});
+                mma4(xQ, wQ, 4, vm, std::integral_constant<int, 3>{});
             };
             unit(std::integral_constant<int, 0>{});
             unit(std::integral_constant<int, 1>{});
