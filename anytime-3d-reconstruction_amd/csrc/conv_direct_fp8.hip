@@ -127,18 +127,23 @@ __global__ __launch_bounds__(512, 1) void conv_direct_fp8_kernel(const unsigned 
                  : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7])               \
                  : "n"(N)                                                                                                       \
                  : "memory")
-#define F8_MFMA4(F)                                                                                                             \
+
+    // one MFMA (weight tile NT x cell tile MT) pinned in place, and one 32-byte operand (two ds_read_b128) of a later tap: the
+    // reads of the next tap sit between the MFMAs of the current one instead of in a burst ahead of them (conv_direct.hip)
+#define F8_MF(F, NT, MT)                                                                                                        \
     do {                                                                                                                        \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                      \
-            const i32x8 wv = {(int)F[4 + 2 * nt][0], (int)F[4 + 2 * nt][1], (int)F[4 + 2 * nt][2], (int)F[4 + 2 * nt][3],       \
-                              (int)F[5 + 2 * nt][0], (int)F[5 + 2 * nt][1], (int)F[5 + 2 * nt][2], (int)F[5 + 2 * nt][3]};      \
-            _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                                  \
-                const i32x8 xv = {(int)F[2 * mt][0], (int)F[2 * mt][1], (int)F[2 * mt][2], (int)F[2 * mt][3],                   \
-                                  (int)F[2 * mt + 1][0], (int)F[2 * mt + 1][1], (int)F[2 * mt + 1][2], (int)F[2 * mt + 1][3]};  \
-                acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[nt][mt], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
-            }                                                                                                                   \
-        }                                                                                                                       \
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));                                  \
+        const i32x8 wv = {(int)F[4 + 2 * NT][0], (int)F[4 + 2 * NT][1], (int)F[4 + 2 * NT][2], (int)F[4 + 2 * NT][3],           \
+                          (int)F[5 + 2 * NT][0], (int)F[5 + 2 * NT][1], (int)F[5 + 2 * NT][2], (int)F[5 + 2 * NT][3]};          \
+        const i32x8 xv = {(int)F[2 * MT][0], (int)F[2 * MT][1], (int)F[2 * MT][2], (int)F[2 * MT][3],                           \
+                          (int)F[2 * MT + 1][0], (int)F[2 * MT + 1][1], (int)F[2 * MT + 1][2], (int)F[2 * MT + 1][3]};          \
+        acc[NT][MT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[NT][MT], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+        asm volatile("" : "+v"(acc[NT][MT]));                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    } while (0)
+#define F8_RD2(FA, FB, A, OFF)                                                                                                  \
+    do {                                                                                                                        \
+        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4"                                          \
+                     : "=&v"(FA), "=&v"(FB) : "v"(A), "v"((A) ^ 16u), "n"(OFF) : "memory");                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
     } while (0)
 
@@ -157,22 +162,33 @@ __global__ __launch_bounds__(512, 1) void conv_direct_fp8_kernel(const unsigned 
             const int c = q * 4 + J;
             const unsigned wsel = (c % F8_NST) * F8_WST, wnext = ((c + 1) % F8_NST) * F8_WST;
             const unsigned xcur = xo[AH] + tsel, wcur = wo[1] + wsel;
-            F8_LDFRAG(Q, xcur, TO1, wcur);
-            F8_WAITFRAG(P, 8);
-            F8_MFMA4(P);                           // first tap of the pair
+            F8_WAITFRAG(P, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            F8_MF(P, 0, 0);                        // first tap of the pair
+            F8_RD2(Q[0], Q[1], xcur, TO1); F8_RD2(Q[4], Q[5], wcur, 0);
+            F8_MF(P, 0, 1);
+            F8_RD2(Q[2], Q[3], xcur, TO1 + 4 * 9 * F8_RB); F8_RD2(Q[6], Q[7], wcur, 4096);
+            F8_MF(P, 1, 0);
+            F8_MF(P, 1, 1);
             F8_WAITFRAG(Q, 0);                     // every LDS read of chunk c has returned: its stage may be refilled
             // chunk c+1's weights (and, before the first tap of the next phase, the whole next tile) have landed.  Issued after
             // w(c+1): [the tile pieces of the previous chunk's slot: 2, 1, 1, 0 for J = 0..3] w(c+2) x2; chunk 3 also needs the
             // piece of chunk 2, which precedes w(c+2).
             wait_vm<(J == 1) ? 4 : (J == 2 ? 3 : 2)>();
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            F8_MF(Q, 0, 0);                        // second tap
             if (J == 0) { issue_x(q + 1, 0); issue_x(q + 1, 1); }
             else if (J == 1) issue_x(q + 1, 2);
             else if (J == 2) issue_x(q + 1, 3);
             issue_w(c + 3);
             const unsigned xnext = xo[AHN] + (J == 3 ? tnext : tsel), wnx = wo[0] + wnext;
-            F8_LDFRAG(P, xnext, TON, wnx);
-            F8_MFMA4(Q);                           // second tap
+            __builtin_amdgcn_sched_barrier(0);
+            F8_MF(Q, 0, 1);
+            F8_RD2(P[0], P[1], xnext, TON); F8_RD2(P[4], P[5], wnx, 0);
+            F8_MF(Q, 1, 0);
+            F8_RD2(P[2], P[3], xnext, TON + 4 * 9 * F8_RB); F8_RD2(P[6], P[7], wnx, 4096);
+            F8_MF(Q, 1, 1);
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
@@ -183,8 +199,9 @@ __global__ __launch_bounds__(512, 1) void conv_direct_fp8_kernel(const unsigned 
     wait_vm<0>();                                   // trailing zero-fill pieces still target LDS
     __syncthreads();
 #undef F8_LDFRAG
+#undef F8_MF
+#undef F8_RD2
 #undef F8_WAITFRAG
-#undef F8_MFMA4
 
     // ---- epilogue: lane = output (wm, mt, fr); registers walk channels
     char *stage = smem;

@@ -267,13 +267,6 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
 #define CW16_MF(F, COT, CT)                                                                                                         \
     acc[COT][CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + COT]),                          \
                                                            *reinterpret_cast<const bf16x8 *>(&F[CT]), acc[COT][CT], 0, 0, 0)
-#define CW16_MFMA(F)                                                                                                                \
-    do {                                                                                                                            \
-        _Pragma("unroll") for (int cot = 0; cot < 4; ++cot) _Pragma("unroll") for (int ct = 0; ct < 4; ++ct)                        \
-            acc[cot][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + cot]),                  \
-                                                                   *reinterpret_cast<const bf16x8 *>(&F[ct]), acc[cot][ct], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                                          \
-    } while (0)
 
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,

@@ -1,5 +1,5 @@
 """A/B of two library builds on the chip-wide MFMA layers at batch 256, back to back and interleaved: D4 (vv_convT3d_k4s2_whole_fwd),
-E2 (vv_conv3d_k4s2_direct_fwd), E3 / D3 (vv_conv3d_k4s2_skip_fwd / vv_convT3d_k4s2_skip_fwd).  Outputs must be bit-identical.
+E2 (vv_conv3d_k4s2_direct_fwd; E2fp8: vv_conv3d_k4s2_direct_fp8_fwd), E3 / D3 (vv_conv3d_k4s2_skip_fwd / vv_convT3d_k4s2_skip_fwd).  Outputs must be bit-identical.
 usage: mb_ab_lib.py <other lib .so> [name]      (the tree's library is 'tree')"""
 import ctypes, json, os, sys, time
 import torch
@@ -41,6 +41,13 @@ cases['E3'] = ('vv_conv3d_k4s2_skip_fwd', lambda y: (L.ptr(x3), L.ptr(w3), L.ptr
 w4 = packed('vv_pack_convT_k4s2_skip', 128, 256, 256, 128)
 x4 = bf(B, 4, 4, 4, 256)
 cases['D3'] = ('vv_convT3d_k4s2_skip_fwd', lambda y: (L.ptr(x4), L.ptr(w4), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 4, 256, 128, 1, L.VV_BF16, cs), (B, 8, 8, 8, 128))
+
+# E2 in fp8 (the direct fp8 kernel of the 'wide' policy): e4m3fn input and weights, bf16 output
+w2f = torch.empty(64 * 64 * 128, dtype=torch.uint8, device=DEV)
+_w2 = (torch.randn(4, 4, 4, 64, 128, device=DEV) / 64).float().contiguous()
+L.call('vv_pack_conv_k4', L.ptr(_w2), L.ptr(w2f), 64, 128, L.VV_FP8, cs)
+x2f = torch.randn(B, 16, 16, 16, 64, device=DEV).to(torch.float8_e4m3fn)
+cases['E2fp8'] = ('vv_conv3d_k4s2_direct_fp8_fwd', lambda y: (L.ptr(x2f), L.ptr(w2f), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 16, 64, 128, 1, L.VV_BF16, cs), (B, 8, 8, 8, 128))
 
 only = os.environ.get('AB_ONLY', '').split(',') if os.environ.get('AB_ONLY') else list(cases)
 N = 300
