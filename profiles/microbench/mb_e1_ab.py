@@ -3,7 +3,9 @@ import torch
 _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'anytime-3d-reconstruction_amd'))
 from voxvae import lib as L
 new = L.load()
-libs = {'tree': new, 'nt': ctypes.CDLL(os.path.join(_R, 'scratch/nt/libvoxvae_nt.so'))}
+# usage: mb_e1_ab.py [other lib .so] [name]   (default: the nontemporal-store build of round 3 under scratch/nt)
+OTHER = sys.argv[2] if len(sys.argv) > 2 else 'nt'
+libs = {'tree': new, OTHER: ctypes.CDLL(os.path.join(_R, sys.argv[1] if len(sys.argv) > 1 else 'scratch/nt/libvoxvae_nt.so'))}
 DEV = 'cuda:0'; B = 256
 x = (torch.rand(B, 32, 32, 32, 1, device=DEV) < 0.1).float().contiguous()
 w = (torch.randn(4, 4, 4, 1, 64, device=DEV) / 8).float().contiguous()
@@ -16,7 +18,7 @@ def launch(k):
     f = libs[k].vv_conv3d_first_fwd; f.restype = ctypes.c_int
     assert f(L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(ys[k]), B, 32, 64, 1, L.VV_BF16, cs) == 0
 for k in libs: launch(k)
-torch.cuda.synchronize(); print('equal', torch.equal(ys['tree'], ys['nt']))
+torch.cuda.synchronize(); print('equal', torch.equal(ys['tree'], ys[OTHER]))
 big = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
 N = 200
 for rep in range(3):

@@ -776,11 +776,23 @@ def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
         L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 32, 64, 1, L.VV_BF16, _st())
         torch.cuda.synchronize()
         return y
-    y0, y1 = e1(), e1()
+    y0, y1 = e1(), e1()                                # the chained plane form (four consecutive output planes per workgroup)
     monkeypatch.setenv('VV_FIRSTCONV_GATHER', '1')
     yg = e1()
     monkeypatch.delenv('VV_FIRSTCONV_GATHER')
-    assert torch.equal(y0, yg) and torch.equal(y1, yg)
+    monkeypatch.setenv('VV_FIRSTCONV_NOCHAIN', '1')
+    yp = e1()                                          # the plane form that loads all four input planes per item
+    monkeypatch.delenv('VV_FIRSTCONV_NOCHAIN')
+    assert torch.equal(y0, yg) and torch.equal(y1, yg) and torch.equal(yp, yg)
+    # chains of two (batch 70: 1,120 items) and of three (batch 130: they cross sample boundaries, so an item in the middle of a
+    # chain has no predecessor in its sample and loads both halves) on a slice of the same input
+    for Bc in (70, 130):
+        def e1c():
+            y = torch.full((Bc, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
+            L.call('vv_conv3d_first_fwd', L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), Bc, 32, 64, 1, L.VV_BF16, _st())
+            torch.cuda.synchronize()
+            return y
+        assert torch.equal(e1c(), yg[:Bc])
 
     xa = torch.randn(B, 16, 16, 16, 64, device=DEV, generator=g).to(torch.bfloat16)
     w5 = (torch.randn(4, 4, 4, 1, 64, device=DEV, generator=g) / 16).contiguous()
