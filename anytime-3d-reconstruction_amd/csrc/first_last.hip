@@ -755,22 +755,29 @@ __global__ __launch_bounds__(256, 3) void first_conv_plane_kernel(const float *_
     }
 }
 
-// first_conv, chained plane form (bf16 output, D = 32, at least two consecutive items per workgroup).  One item = one whole output plane
-// od of one sample (256 outputs x 64 channels) from input planes 2 od - 1 .. 2 od + 2; the NEXT output plane of the same sample needs
-// 2 od + 1 .. 2 od + 4: half of what is already in LDS.  The plane form above loads all four planes for every item (16 planes per
-// four-item workgroup, every input plane fetched twice chip-wide); here the tile is a ring of four HALF tiles (two planes each), an
+// first_conv, chained plane form (D = 32 or 64, bf16 or e4m3fn output, at least two consecutive items per workgroup).  One item =
+// 256 outputs x 64 channels of ONE output plane od (D = 32: the whole 16 x 16 plane; D = 64: 8 of its 32 rows) from input planes
+// 2 od - 1 .. 2 od + 2; the next output plane of the same sample (and row block) needs 2 od + 1 .. 2 od + 4: half of what is
+// already in LDS.  The plane form above loads all four planes for every item (16 planes per four-item workgroup, every input plane
+// fetched twice chip-wide); here the items are ordered with od fastest, the tile is a ring of four HALF tiles (two planes each), an
 // item takes its first half from its predecessor's second one and only the two new planes travel (10 planes per four-item
 // workgroup): 37 % fewer load instructions, conversions and LDS writes, 12 instead of 20 prefetch registers -- which is what lets
 // FOUR workgroups per CU fit in 128 VGPRs without scratch (the plane form had drifted to 134 = three per CU under a launcher that
-// still dealt the items for four: a 1.33-round grid).  Loads go through a buffer descriptor: a slot in the SAME padding (plane -1 / 32,
-// rows -1 / 32) or past the slot list reads offset 0xFFFFFFF0 and comes back as zeros, no exec-masked branch per load.
+// still dealt the items for four: a 1.33-round grid).  Loads go through a buffer descriptor: a slot in the SAME padding (plane -1 / D,
+// rows -1 / D) or past the slot list reads offset 0xFFFFFFF0 and comes back as zeros, no exec-masked branch per load.  The e4m3fn
+// output goes from registers to memory as well (two v_permlane32_swap per 32 channels give a lane 16 consecutive channels = one
+// 16-byte store): no 32 KiB transpose stage, no second barrier, four workgroups per CU instead of three.
 // Ring safety with ONE barrier per item: item j reads halves (A_j, B_j); the halves written at the top of item j + 1 are the next one
 // or two ring positions, never A_j or B_j (four positions), and nobody is behind item j (everyone passed barrier j + 1's predecessor).
-__global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp,
-                                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                    __bf16 *__restrict__ y, int batch, int act, int items_per_wg) {
-    constexpr int COUT = 64, LI = 5, D = 32, OW = 16, R = 34, PD = 18, PP = R * PD, HALF = 2 * PP;   // dwords per plane / per half tile
-    constexpr int NIH = (2 * R * 8 + 255) / 256;           // float4 slots per thread and half: 544 -> 3
+template <int LI, bool OUT8>
+__global__ __launch_bounds__(256, 4) void first_conv_chain_kernel(const float *__restrict__ x, const __bf16 *__restrict__ wp,
+                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                  void *__restrict__ y, int batch, int act, int items_per_wg) {
+    constexpr int COUT = 64, D = 1 << LI, LO = LI - 1, OW = 1 << LO, OH = 256 / OW, LHB = LO - (8 - LO);   // hblocks = OW / OH = 2^LHB
+    constexpr int R = 2 * OH + 2, PD = OW + 2, PP = R * PD, HALF = 2 * PP;   // tile rows per plane, dwords per row / plane / half tile
+    constexpr int QPR = D / 4, LQ = LI - 2;                // float4 per input row
+    constexpr int NIH = (2 * R * QPR + 255) / 256;         // float4 slots per thread and half (544 / 576 -> 3)
+    constexpr int ROW = COUT * (OUT8 ? 1 : 2);             // bytes per output voxel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -779,29 +786,37 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
     uint4 *wl = reinterpret_cast<uint4 *>(ss + 128);       // weights as A fragments [ks][nt][lane]
     if (tid < 64) ss[tid] = scale ? scale[tid] : 1.f;
     else if (tid < 128) ss[tid] = shift ? shift[tid - 64] : 0.f;
-    const long nitems = (long)batch * OW;
+    const long nitems = ((long)batch << LO) << LHB;
 
-    const int m4 = tid & 7;                                // float4 column of every slot of this thread
-    int loff[NIH], pl[NIH];                                // dword offset inside a half (-1: no slot); plane of the half, or -64 when the row is padding
-    unsigned soff[NIH];                                    // byte offset from (first plane of the half, row -1, column 0)
+    const int m4 = tid & (QPR - 1);                        // float4 column of every slot of this thread
+    int loff[NIH], pl[NIH], rr[NIH];                       // dword offset inside a half (-1: no slot); plane of the half (-4 D: none); tile row
+    unsigned soff[NIH];                                    // byte offset from (first plane of the half, first tile row, column 0)
 #pragma unroll
     for (int i = 0; i < NIH; ++i) {
-        const int s = tid + 256 * i, row = s >> 3, p = row >= R ? 1 : 0, rr = row - p * R;
-        const bool slot = s < 2 * R * 8;
-        loff[i] = slot ? (p * R + rr) * PD + 2 * m4 : -1;
-        pl[i] = slot && (unsigned)(rr - 1) < (unsigned)D ? p : -64;
-        soff[i] = (unsigned)((((p << LI) + rr) << LI) + 4 * m4) * 4u;
+        const int s = tid + 256 * i, row = s >> LQ, p = row >= R ? 1 : 0;
+        const bool slot = s < 2 * R * QPR;
+        rr[i] = row - p * R;
+        loff[i] = slot ? (p * R + rr[i]) * PD + 2 * m4 : -1;
+        pl[i] = slot ? p : -4 * D;
+        soff[i] = (unsigned)((((p << LI) + rr[i]) << LI) + 4 * m4) * 4u;
     }
     const int fr = lane & 31, fh = lane >> 5;
     for (int i = wave; i < 8; i += 4)                      // i = ks*2 + nt
         wl[i * 64 + lane] = *reinterpret_cast<const uint4 *>(wp + ((i & 1) * 32 + fr) * 64 + (i >> 1) * 16 + 8 * fh);
 
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)(((unsigned)batch << (3 * LI)) * 4u), 0x00020000);
-    auto load_half = [&](int b, int d, f32x4 (&r)[NIH]) {  // planes d, d + 1 of sample b, rows -1 .. 32
-        const unsigned base = (unsigned)(((((b << LI) + d) << LI) - 1) << LI) * 4u;      // wraps below zero for d = -1; valid slots land back in range
+    // item -> (sample, row block, output plane), od fastest
+    auto decode = [&](long item, int &b, int &hb, int &od) {
+        od = (int)(item & (OW - 1));
+        hb = (int)(item >> LO) & ((1 << LHB) - 1);
+        b = (int)(item >> (LO + LHB));
+    };
+    auto load_half = [&](int b, int hb, int d, f32x4 (&r)[NIH]) {   // planes d, d + 1 of sample b, tile rows of row block hb
+        const int h0 = 2 * hb * OH - 1;
+        const unsigned base = (unsigned)(((((b << LI) + d) << LI) + h0) << LI) * 4u;     // wraps below zero for d / h0 = -1; valid slots land back in range
 #pragma unroll
         for (int i = 0; i < NIH; ++i) {
-            const bool ok = (unsigned)(d + pl[i]) < (unsigned)D;
+            const bool ok = (unsigned)(d + pl[i]) < (unsigned)D && (unsigned)(h0 + rr[i]) < (unsigned)D;
             // (whole-vector bit cast: __builtin_bit_cast(float, v[k]) on a vector ELEMENT reads element 0 for every k with this compiler)
             r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(ok ? base + soff[i] : 0xFFFFFFF0u), 0, 0));
         }
@@ -819,7 +834,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
             if (loff[i] >= 0) {
                 unsigned *dst = half + loff[i];
                 *reinterpret_cast<uint2 *>(dst) = make_uint2(pack2(left, r[i][0]), pack2(r[i][1], r[i][2]));
-                if (m4 == 7) dst[2] = pack2(r[i][3], 0.f);
+                if (m4 == QPR - 1) dst[2] = pack2(r[i][3], 0.f);
             }
         }
     };
@@ -827,15 +842,20 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
     const long item0 = (long)blockIdx.x * items_per_wg;
     const long item_end = item0 + items_per_wg < nitems ? item0 + items_per_wg : nitems;
     f32x4 raw[NIH];                                        // the second half (planes 2 od + 1, 2 od + 2) of the item about to run
-    if (item0 < item_end) load_half((int)(item0 >> 4), 2 * (int)(item0 & 15) + 1, raw);
+    if (item0 < item_end) {
+        int b, hb, od;
+        decode(item0, b, hb, od);
+        load_half(b, hb, 2 * od + 1, raw);
+    }
     auto run = [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
     int nxt = 0, hA = 0, hB = 0;
     for (long item = item0; item < item_end; ++item) {
-        const int b = (int)(item >> 4), od = (int)(item & 15);
-        if (item == item0 || od == 0) {                    // no predecessor in this workgroup / in this sample: planes 2 od - 1, 2 od as well
+        int b, hb, od;
+        decode(item, b, hb, od);
+        if (item == item0 || od == 0) {                    // no predecessor in this workgroup / for this row block: planes 2 od - 1, 2 od as well
             f32x4 ra[NIH];
-            load_half(b, 2 * od - 1, ra);
+            load_half(b, hb, 2 * od - 1, ra);
             write_half(nxt, ra);
             hA = nxt;
             nxt = (nxt + 1) & 3;
@@ -844,8 +864,13 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
         hB = nxt;
         nxt = (nxt + 1) & 3;
         __syncthreads();
-        if (item + 1 < item_end) load_half((int)((item + 1) >> 4), 2 * (int)((item + 1) & 15) + 1, raw);
+        if (item + 1 < item_end) {
+            int nb, nhb, nod;
+            decode(item + 1, nb, nhb, nod);
+            load_half(nb, nhb, 2 * nod + 1, raw);
+        }
         const unsigned *tA = ring + hA * HALF, *tB = ring + hB * HALF;
+        const long oitem = ((((long)b << LO) + od) << LHB) + hb;      // the output is (sample, plane, row block) major
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x16 acc[2];                                  // [nt]
@@ -853,7 +878,7 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
-            const int o = (wave * 2 + mt) * 32 + fr, ohl = o >> 4, ow = o & (OW - 1);
+            const int o = (wave * 2 + mt) * 32 + fr, ohl = o >> LO, ow = o & (OW - 1);
             const int ti = (2 * ohl + 2 * fh) * PD + ow;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -866,27 +891,41 @@ __global__ __launch_bounds__(256, 4) void first_conv_chain32_kernel(const float 
                                                                       *reinterpret_cast<const bf16x8 *>(&xf), acc[nt], 0, 0, 0);
                 }
             }
-            // folded BN + activation, v_permlane32_swap pairs, 16-byte stores: as in the plane form
-            char *yo = reinterpret_cast<char *>(y) + item * (256 * COUT * 2) + o * (COUT * 2) + fh * 16;
+            // folded BN + activation; lanes fr / fr + 32 hold channels 8g + 0..3 / 8g + 4..7 of output o
+            char *yo = reinterpret_cast<char *>(y) + oitem * (256 * ROW) + o * ROW;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 u32x2 oq[4];
+                unsigned o8[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = nt * 32 + 8 * g + 4 * fh;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(ss + c), sh = *reinterpret_cast<const f32x4 *>(ss + 64 + c);
                     f32x4 tv = f32x4{acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
                     tv = vv_bn_act4<ACT>(tv, sc, sh);
-                    bf16x4 ov;
+                    if constexpr (OUT8) o8[g] = vv_pack_fp8x4(tv);
+                    else {
+                        bf16x4 ov;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = static_cast<__bf16>(tv[e]);
-                    oq[g] = *reinterpret_cast<const u32x2 *>(&ov);
+                        for (int e = 0; e < 4; ++e) ov[e] = static_cast<__bf16>(tv[e]);
+                        oq[g] = *reinterpret_cast<const u32x2 *>(&ov);
+                    }
                 }
+                if constexpr (OUT8) {
+                    // dword g of lane half fh = channels 8g + 4fh .. + 3.  swap(g + 2, g): the upper half of dword g + 2 goes to the lower
+                    // lanes' dword g and back -- lower lanes end with (g + 2: fh 0, fh 1) = 8 consecutive channels of group g + 2, upper
+                    // lanes with those of group g: lane half 0 stores channels 16 .. 31, lane half 1 channels 0 .. 15 of this 32-block
+                    auto r0 = __builtin_amdgcn_permlane32_swap(o8[2], o8[0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(o8[3], o8[1], false, false);
+                    *reinterpret_cast<u32x4 *>(yo + nt * 32 + (1 - fh) * 16) = u32x4{r0[0], r0[1], r1[0], r1[1]};
+                } else {
+                    // swapping the upper half of quad 2j with the lower half of quad 2j + 1 gives every lane 8 consecutive channels (guide T21)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    auto rx = __builtin_amdgcn_permlane32_swap(oq[2 * j][0], oq[2 * j + 1][0], false, false);
-                    auto ry = __builtin_amdgcn_permlane32_swap(oq[2 * j][1], oq[2 * j + 1][1], false, false);
-                    *reinterpret_cast<u32x4 *>(yo + nt * 64 + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                    for (int j = 0; j < 2; ++j) {
+                        auto rx = __builtin_amdgcn_permlane32_swap(oq[2 * j][0], oq[2 * j + 1][0], false, false);
+                        auto ry = __builtin_amdgcn_permlane32_swap(oq[2 * j][1], oq[2 * j + 1][1], false, false);
+                        *reinterpret_cast<u32x4 *>(yo + fh * 16 + nt * 64 + j * 32) = u32x4{rx[0], ry[0], rx[1], ry[1]};
+                    }
                 }
             }
         }
@@ -1055,16 +1094,24 @@ int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float 
         const size_t lds = tile_b + (out_fp8 ? (size_t)256 * (64 * 2) : tile_b) + 128 * sizeof(float) + 8 * 64 * 16;
         const int nslots = 4 * r * (side / 4), ni = (nslots + 255) / 256;
         static const long envwg = getenv("VV_FIRSTCONV_WGS") ? atol(getenv("VV_FIRSTCONV_WGS")) : 0;
-        // D = 32, bf16 output, batches that give every workgroup a chain of >= 2 consecutive output planes: the chained kernel, FOUR
-        // persistent workgroups per CU (batch 256: 4,096 items = 1,024 x 4); its input offsets are 32-bit (< 2 GiB of input per launch)
+        // D = 32 / 64 and batches that give every workgroup a chain of >= 2 consecutive output planes: the chained kernel, FOUR persistent
+        // workgroups per CU (D = 32, batch 256: 4,096 items = 1,024 x 4); its input offsets are 32-bit (< 2 GiB of input per launch)
         const bool nochain = getenv("VV_FIRSTCONV_NOCHAIN") != nullptr;      // test hook: the plane form at every batch
-        if (side == 32 && !out_fp8 && !nochain && (size_t)batch * side * side * side * sizeof(float) < 0x7FFFFFFFull) {
+        if ((side == 32 || side == 64) && !nochain && (size_t)batch * side * side * side * sizeof(float) < 0x7FFFFFFFull) {
             const long maxwg4 = envwg > 0 ? envwg : 256 * 4;
             const int ipw4 = (int)((nitems + maxwg4 - 1) / maxwg4);
             if (ipw4 >= 2) {
-                const size_t lds4 = (size_t)4 * 2 * 34 * 18 * 4 + 128 * sizeof(float) + 8 * 64 * 16;
-                VV_LAUNCH(first_conv_chain32_kernel, dim3((unsigned)((nitems + ipw4 - 1) / ipw4)), dim3(256), lds4, reinterpret_cast<hipStream_t>(stream), x,
-                          reinterpret_cast<const __bf16 *>(w_packed), scale, shift, reinterpret_cast<__bf16 *>(y), batch, act, ipw4);
+                const size_t lds4 = (size_t)4 * 2 * r * pd * 4 + 128 * sizeof(float) + 8 * 64 * 16;
+                const dim3 g4((unsigned)((nitems + ipw4 - 1) / ipw4));
+                hipStream_t st4 = reinterpret_cast<hipStream_t>(stream);
+                const __bf16 *wb4 = reinterpret_cast<const __bf16 *>(w_packed);
+                if (side == 32) {
+                    if (out_fp8) VV_LAUNCH((first_conv_chain_kernel<5, true>), g4, dim3(256), lds4, st4, x, wb4, scale, shift, y, batch, act, ipw4);
+                    else VV_LAUNCH((first_conv_chain_kernel<5, false>), g4, dim3(256), lds4, st4, x, wb4, scale, shift, y, batch, act, ipw4);
+                } else {
+                    if (out_fp8) VV_LAUNCH((first_conv_chain_kernel<6, true>), g4, dim3(256), lds4, st4, x, wb4, scale, shift, y, batch, act, ipw4);
+                    else VV_LAUNCH((first_conv_chain_kernel<6, false>), g4, dim3(256), lds4, st4, x, wb4, scale, shift, y, batch, act, ipw4);
+                }
                 return vv_launch_status();
             }
         }

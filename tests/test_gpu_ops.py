@@ -964,6 +964,37 @@ def test_conv3d_first_fp8_output(L, B, D):
     assert L.load().vv_conv3d_first_fwd_io(L.ptr(xd), L.ptr(wp), L.ptr(sd), L.ptr(hd), L.ptr(y), B, 16, 64, 1, L.VV_BF16, L.VV_FP8, _st()) == -3   # VV_ERR_DTYPE
 
 
+@pytest.mark.parametrize('out', ['bf16', 'fp8'])
+@pytest.mark.parametrize('B,D,act', [(70, 32, 1), (130, 32, 0), (200, 32, 2), (9, 64, 1), (20, 64, 0), (40, 64, 1)])
+def test_conv3d_first_chained_equals_plane_form(L, monkeypatch, out, B, D, act):
+    """The chained first layer (an output plane takes two of its four input planes from its predecessor in the workgroup; ring of
+    half tiles, buffer-descriptor loads, register-to-memory e4m3fn stores) against the plane form that loads all four planes per
+    item, bit for bit: chains of 2, 3 (they cross plane-0 boundaries: an item in the middle of a chain without a predecessor),
+    4 and 5, both grid sizes, both output types, every activation template."""
+    if out == 'fp8' and F8 is None:
+        pytest.skip('torch.float8_e4m3fn not available')
+    g = torch.Generator(device=DEV).manual_seed(B + D)
+    x = (torch.rand(B, D, D, D, 1, device=DEV, generator=g) < 0.15).float().contiguous()
+    w = (torch.randn(4, 4, 4, 1, 64, device=DEV, generator=g) / 8).contiguous()
+    sc = torch.rand(64, device=DEV, generator=g) + 0.5
+    sh = torch.randn(64, device=DEV, generator=g) * 0.3
+    wp = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_conv_k4', L.ptr(w), L.ptr(wp), 1, 64, L.VV_BF16, _st())
+    odt, tdt = (L.VV_FP8, torch.uint8) if out == 'fp8' else (L.VV_BF16, torch.int16)
+
+    def run():
+        y = torch.full((B, D // 2, D // 2, D // 2, 64), 0x55, dtype=tdt, device=DEV)
+        L.call('vv_conv3d_first_fwd_io', L.ptr(x), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, D, 64, act, L.VV_BF16, odt, _st())
+        torch.cuda.synchronize()
+        return y
+    monkeypatch.delenv('VV_FIRSTCONV_NOCHAIN', raising=False)
+    a = run()
+    monkeypatch.setenv('VV_FIRSTCONV_NOCHAIN', '1')
+    b = run()
+    monkeypatch.delenv('VV_FIRSTCONV_NOCHAIN')
+    assert torch.equal(a, b)
+
+
 @pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
 @pytest.mark.parametrize('B,side,act', [(1, 8, 1), (3, 8, 0), (2, 16, 1), (1, 32, 2)])
 def test_convT3d_direct_fp8(L, B, side, act):
