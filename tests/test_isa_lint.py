@@ -57,6 +57,25 @@ def test_no_in_flight_asm_output_is_touched_and_ring_depths_hold(src):
             assert r['meta'].get('private_segment_fixed_size', 0) == 0 and r['meta'].get('vgpr_spill_count', 0) == 0, (kernel, r['meta'])
 
 
+# kernel family -> (source, VGPR budget): launchers that deal the work items for a fixed number of workgroups per CU.  The first layer's
+# plane form was written for four per CU (128 VGPRs); removing its timing ablations let the register allocator drift to 134 = three per
+# CU under a launcher that still dealt for four (a 1.33-round grid, ~20 % of the kernel) and nothing noticed for a round.
+RESIDENT_BUDGET = {'first_conv_chain_kernel': ('first_last.hip', 128), 'final_bce_sweep_kernel': ('first_last.hip', 168)}
+
+
+def test_kernels_dealt_for_a_fixed_residency_keep_their_register_budget():
+    seen = set()
+    for fam, (src, budget) in RESIDENT_BUDGET.items():
+        for kernel, fn in il.parse(il.compile_isa(os.path.join(il.CSRC, src))).items():
+            if _family(kernel) != fam:
+                continue
+            seen.add(fam)
+            m = fn['meta']
+            assert m.get('vgpr_count', 0) <= budget, (kernel, m)
+            assert m.get('private_segment_fixed_size', 0) == 0 and m.get('vgpr_spill_count', 0) == 0, (kernel, m)
+    assert seen == set(RESIDENT_BUDGET), seen
+
+
 # ------------------------------------------------------------------------------------------------ the walker on known shapes
 _HEAD = '''\t.text
 _Z1kv:
