@@ -965,12 +965,12 @@ def test_conv3d_first_fp8_output(L, B, D):
 
 
 @pytest.mark.parametrize('out', ['bf16', 'fp8'])
-@pytest.mark.parametrize('B,D,act', [(70, 32, 1), (130, 32, 0), (200, 32, 2), (9, 64, 1), (20, 64, 0), (40, 64, 1)])
+@pytest.mark.parametrize('B,D,act', [(65, 32, 1), (70, 32, 1), (130, 32, 0), (200, 32, 2), (255, 32, 1), (257, 32, 3), (9, 64, 1), (20, 64, 0), (40, 64, 1), (67, 64, 1)])
 def test_conv3d_first_chained_equals_plane_form(L, monkeypatch, out, B, D, act):
     """The chained first layer (an output plane takes two of its four input planes from its predecessor in the workgroup; ring of
     half tiles, buffer-descriptor loads, register-to-memory e4m3fn stores) against the plane form that loads all four planes per
     item, bit for bit: chains of 2, 3 (they cross plane-0 boundaries: an item in the middle of a chain without a predecessor),
-    4 and 5, both grid sizes, both output types, every activation template."""
+    4, 5 and 9 (ragged last workgroups: batches 65, 255, 257, 67), both grid sizes, both output types, every activation template."""
     if out == 'fp8' and F8 is None:
         pytest.skip('torch.float8_e4m3fn not available')
     g = torch.Generator(device=DEV).manual_seed(B + D)
