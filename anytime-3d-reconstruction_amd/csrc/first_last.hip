@@ -2,6 +2,7 @@
 //   final_bce  : Conv3DTranspose k4 s2 SAME -> 1 channel, sigmoid, weighted BCE and TP/FP/FN, fused
 //                (autoencoder3D.py:129-136; function.py:73-82, 100-115)
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -459,6 +460,227 @@ __global__ __launch_bounds__(256, SW_DEPTH == 1 ? 3 : 2) void final_bce_sweep_ke
         }
         acc[0] = acc_next[0];
         acc[1] = acc_next[1];
+        oldh = nexth;
+        __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
+    bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
+    if (lane == 0) { red[wv][0] = bce; red[wv][1] = tp; red[wv][2] = fp; red[wv][3] = fn; }
+    __syncthreads();
+    if (tid < 4) partials[((size_t)b * ntile + tile) * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// final_bce, sweep form with the w direction summed INSIDE the MFMA (bf16, round 3).  The sweep kernel above publishes P[halo cell][64 taps]
+// (25.6 KB of float32 per plane) and every output gathers 8 terms from it; its ablations put the memory side of the
+// layer at 31 us and the float32 round trip of P through LDS (written at the LDS write rate, gathered as whole tap quads) at most of the
+// other 20.  The two w terms of an output column share their centre cell: out[2i] = x_i w[tw 1] + x_{i-1} w[tw 3], out[2i+1] = x_{i+1} w[tw 0]
+// + x_i w[tw 2].  With K = 128 = (centre | left) resp. (right | centre) channels and the 16 (td, th) pairs as the MFMA's rows
+// (v_mfma_f32_16x16x32_bf16), the matrix pipe delivers Q[centre cell][td][th][pw] -- the same FLOPs, float32 sums as before, but 80 cells x 32
+// values = 10 KB per plane instead of 100 x 64, and an output pair reads ONE 8-byte granule per (ah, td) instead of three 16-byte quads:
+// LDS written / 2.5, gathered / 6, 38 KB of LDS and <= 128 VGPRs = four workgroups per CU.  Staging, the counted waits and the voxel math
+// are the sweep kernel's, unchanged.
+constexpr int SWW_LDS = SW_NX * SW_XB + 1024 + 80 * 128;
+__global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *__restrict__ x, const float *__restrict__ w,
+                                                                 const float *__restrict__ target, float *__restrict__ probs,
+                                                                 float *__restrict__ logits, float *__restrict__ partials,
+                                                                 int din_log2, unsigned x_bytes, float gamma, float epsilon) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Xs = smem;                                             // ring of SW_NX planes x [104 rows][128 B], slot-swizzled; 1 KiB sink
+    char *Pq = smem + SW_NX * SW_XB + 1024;                      // Q_d [80 centre cells][td 4][th 4][pw 2] float32, 8-byte granule g at g ^ key(cell)
+    __shared__ float red[4][4];
+    const int li = din_log2, n = 1 << li, nt8 = n >> 3, ntile = nt8 * nt8;
+    const int T = gridDim.x;
+    const int wi = (T & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (T >> 3) + (int)(blockIdx.x >> 3);
+    const int tile = wi % ntile, b = wi / ntile;
+    const int h0 = (tile / nt8) * 8, w0 = (tile % nt8) * 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const u32x4 rs = vv_make_rsrc(x, x_bytes);
+    const unsigned ldsx = (unsigned)(unsigned long long)(lptr_t)Xs;
+    // plane d -> ring slot d % 3: 13 pieces of 8 rows; every wave issues 4 (the 3 surplus ones go to the sink so that the
+    // vector-memory counter advances uniformly); rows >= 100, voxels outside the grid and planes outside [0, n) arrive
+    // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
+    // the slot: whatever it finds there only reaches accumulator rows >= 104, which are never published.
+    // The lane part of a piece's source offset (sample, halo row, swizzled slot; out-of-range if the row is outside the grid
+    // or past the 100 halo rows) is prepared once; the plane rides in soffset.
+    unsigned sv[4], sdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wv * 4 + i, row = piece * 8 + (lane >> 3);
+        const int zh = row / 10, zw = row - zh * 10;
+        const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+        const bool ok = row < SW_ROWS && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+        const int g = (lane & 7) ^ ((row >> 1) & 7);
+        sv[i] = ok ? (unsigned)(((((b << li) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
+        sdst[i] = piece < 13 ? (unsigned)(piece * 1024) : (unsigned)(SW_NX * SW_XB);     // surplus pieces: the sink (ring-slot independent)
+    }
+    auto stage = [&](int d, int sp) {              // sp = d % SW_NX, passed so that the unrolled steps see a constant
+        // a plane outside [0, n): every lane out of range by its OFFSET.  (A descriptor of zero records is not a substitute: the
+        // zero-fill of the virtual plane d = n then went missing now and then and od = 2n - 1 read the stale slot -- found by the
+        // B = 256 cross-check against the box form, profiles/microbench/chk_e1_d5.py.)
+        const bool din = (unsigned)d < (unsigned)n;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(din ? (d << (2 * li)) * (FB_CIN * 2) : 0);
+        const unsigned slot = ldsx + sp * SW_XB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vv_dma16(rs, din ? sv[i] : 0xFFFFFFF0u, soff, wv * 4 + i < 13 ? slot + sdst[i] : ldsx + sdst[i]);
+    };
+    stage(0, 0);
+
+    // Weights as the first MFMA operand (16 rows n = td * 4 + th, K = 128): for output-column parity pw the K halves are the taps
+    // (tw 1 | tw 3) of (centre | left) for pw = 0 and (tw 0 | tw 2) of (right | centre) for pw = 1; lane (n = lane & 15, kq = lane >> 4)
+    // holds 8 input channels of k-step ks, straight from the Keras array [64 taps][64 ci]
+    const int c16 = lane & 15, kq = lane >> 4;
+    uint4 wf[2][4];
+#pragma unroll
+    for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int tw = pw == 0 ? (ks < 2 ? 1 : 3) : (ks < 2 ? 0 : 2);
+            const float *wr = w + (c16 * 4 + tw) * FB_CIN + (ks & 1) * 32 + kq * 8;
+            const f32x4 w0v = *reinterpret_cast<const f32x4 *>(wr), w1v = *reinterpret_cast<const f32x4 *>(wr + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = static_cast<__bf16>(w0v[e]); o[4 + e] = static_cast<__bf16>(w1v[e]); }
+            wf[pw][ks] = *reinterpret_cast<const uint4 *>(&o);
+        }
+    // this wave's row tiles: tile T = 16 centre cells (zh = 2T, 2T + 1; zw = 1 .. 8); wave w owns tile w, wave 0 tile 4 as well
+    const int ntl = wv == 0 ? 2 : 1;
+    const int rowC = (2 * wv + (c16 >> 3)) * 10 + 1 + (c16 & 7);     // halo row of this lane's centre cell in tile wv (tile 4: + 80)
+    unsigned xo[3][2];                                           // [centre, left, right][channel half]: byte offset of this lane's operand slot
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) xo[s3][hf] = (unsigned)fm_lds_off(rowC + (s3 == 0 ? 0 : s3 == 1 ? -1 : 1), hf * 4 + kq);
+    // Q row of a centre cell pr = zh * 8 + (zw - 1): 16 granules of 8 B = (pw 0, pw 1) of n = td * 4 + th, granule g stored at g ^ key,
+    // key = ((zw - 1) >> 1) << 1 | (zh & 1) << 3: the 32 lanes of a ds_read_b64 pass (8 columns x 2 row parities x 2 ph) hit 32 different
+    // granule positions of the two bank halves (row parity = column parity picks the half; bit 0 of g = bit 0 of th = 1 - ph)
+    auto qkey = [](int pr) { return (((pr & 7) >> 1) << 1) | (((pr >> 3) & 1) << 3); };
+
+    // gather role: s = od parity slot, ohh = output row inside the tile, mw = cell column (both pw per lane)
+    const int mw = tid & 7, ohh = (tid >> 3) & 15, sl = tid >> 7;
+    const int mh = ohh >> 1, ph = ohh & 1;
+    const int lo = li + 1, n2 = 2 * n;
+    const int oh = 2 * h0 + ohh, ow = 2 * (w0 + mw);
+    const float hi = 1.0f - epsilon;
+    float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
+    float lo0 = 0.f, lo1 = 0.f;                                  // td in {2,3} contributions of P_{d-1} to this step's outputs (P_{-1} = 0)
+
+    // Q_d[n][cell][pw] for this wave's tiles: D[n][cell], weights first, K = (centre | left) / (right | centre) channels
+    auto mfma_plane = [&](int sp, f32x4 (&acc)[2][2]) {           // sp = ring slot of the plane; acc[tile][pw]
+        const char *Xd = Xs + sp * SW_XB;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < ntl) {
+                const char *Xt = Xd + t * (80 * 128);             // tile 4 = tile 0 + 8 halo rows of 10 cells: same slot keys ((row >> 1) + 40)
+                uint4 fc[2], fl[2], fr2[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    fc[hf] = *reinterpret_cast<const uint4 *>(Xt + xo[0][hf]);
+                    fl[hf] = *reinterpret_cast<const uint4 *>(Xt + xo[1][hf]);
+                    fr2[hf] = *reinterpret_cast<const uint4 *>(Xt + xo[2][hf]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                  // the two accumulators alternate: no chain of dependent MFMAs
+                    const uint4 &a0 = ks < 2 ? fc[ks] : fl[ks - 2], &a1 = ks < 2 ? fr2[ks] : fc[ks - 2];
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[0][ks]),
+                                                                        *reinterpret_cast<const bf16x8 *>(&a0), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[1][ks]),
+                                                                        *reinterpret_cast<const bf16x8 *>(&a1), acc[t][1], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // Software pipeline: step d publishes P_d (computed during step d-1) and then runs the MFMAs of plane d+1 in the same
+    // instruction stream as the gather / loss math of plane d (matrix pipe under the VALU and LDS work).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // plane 0
+    __syncthreads();                                             // ... for every wave
+    f32x4 acc[2][2];
+    mfma_plane(0, acc);
+#pragma unroll
+    for (int k = 1; k <= SW_DEPTH; ++k) stage(k, k);
+    __syncthreads();                                             // slot 0 may be refilled from the first step on
+
+    // (Unrolling this loop by two with the step parity as a compile-time constant -- ring slot and P buffer addresses folded
+    // into the instructions -- is worth 2 % (53.5 vs 54.7 us) in the clean kernel; with the ablation switches still compiled in
+    // it returned a low loss sum at B = 256 with exact logits and counts, which is not understood: not used.)
+    int oldh = 0;                                                // ring slot of plane d
+#pragma unroll 1
+    for (int d = 0; d <= n; ++d) {
+        // weights first: lane = centre cell (lane & 15), td = lane >> 4, registers walk th: (th 0, th 1) and (th 2, th 3) with both pw
+        // are two 16-byte stores per tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (t < ntl) {
+                const int pr = (wv + 4 * t) * 16 + c16, key = qkey(pr);
+                char *row = Pq + pr * 128;
+                *reinterpret_cast<f32x4 *>(row + (((4 * kq) ^ key) << 3)) = f32x4{acc[t][0][0], acc[t][1][0], acc[t][0][1], acc[t][1][1]};
+                *reinterpret_cast<f32x4 *>(row + (((4 * kq + 2) ^ key) << 3)) = f32x4{acc[t][0][2], acc[t][1][2], acc[t][0][3], acc[t][1][3]};
+            }
+        const int od = 2 * d - 1 + sl;
+        const bool ovalid = (unsigned)od < (unsigned)n2;
+        const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
+        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
+        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
+        // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
+        //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
+        // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
+        // An asm output is a READY value to the compiler: nothing in the language stops it from copying y or re-using its
+        // registers while the load is in flight.  tests/test_isa_lint.py checks on the generated code that no instruction
+        // names the pair between this load and the counted wait below that lands it ("+v"(y)); round 2's dead ends came from
+        // exactly that (a look-ahead load whose last instance was DEAD: its registers went to the logit accumulators of the
+        // last plane while it was in flight -- DESIGN.md section 4d).  The two compiler-managed alternatives were built in round 3
+        // and are worse: a plain load of the noalias argument is moved by the compiler across the asm statements into the
+        // `ovalid` branch (behind the counted wait, whose count then no longer holds: wrong logits), a volatile load becomes a
+        // system-scope flat load with an immediate vmcnt(0).
+        float2 y;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
+        stage(d + 1 + SW_DEPTH, oldh);
+        // depth 1: [plane d+1 x4][stores d-1][y d][plane d+2 x4] -> all but the newest 5.  depth 2: plane d+1 is followed by
+        // stores d-2 (0..2), y d-1, plane d+2 x4, stores d-1 (0..2), y d, plane d+3 x4 = 10..14 operations -> all but the newest 10
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW_DEPTH == 1 ? 5 : 10) : "memory");         // plane d+1 has landed
+        __syncthreads();                                         // ... for every wave; P_d is published
+
+        f32x4 acc_next[2][2];
+        const int nexth = oldh + 1 == SW_NX ? 0 : oldh + 1;      // ring slot of plane d+1
+        mfma_plane(nexth, acc_next);
+
+        // gather: the w direction is already summed inside Q, so an output pair (pw 0, pw 1) takes ONE 8-byte read per (ah, td): the
+        // td = sl entries complete the output planes od = 2d - 1 + sl together with the td = 2 + sl entries of Q_{d-1}, which were read a
+        // step ago into (lo0, lo1): Q is read in the step that publishes it, so one buffer holds it.
+        float l0 = lo0, l1 = lo1;
+        lo0 = 0.f; lo1 = 0.f;
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {
+            const int zh = mh + ph - ah + 1, th = 1 - ph + 2 * ah;
+            const int pr = zh * 8 + mw, key = qkey(pr);
+            const char *row = Pq + pr * 128;
+            const float2 a = *reinterpret_cast<const float2 *>(row + (((sl * 4 + th) ^ key) << 3));
+            const float2 bq = *reinterpret_cast<const float2 *>(row + ((((2 + sl) * 4 + th) ^ key) << 3));
+            l0 += a.x; l1 += a.y;
+            lo0 += bq.x; lo1 += bq.y;
+        }
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(y) : : "memory");   // y has landed; plane d+2 may still be in flight
+        if (ovalid) {
+            const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
+            float p[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                p[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-l[e]));
+                const float q = fminf(fmaxf(p[e], epsilon), hi);
+                bce -= gamma * yy[e] * __logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * __logf(1.0f - q);
+                const float yh = l[e] >= 0.f ? 1.f : 0.f;
+                tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
+            }
+            if (probs) *reinterpret_cast<float2 *>(probs + o) = make_float2(p[0], p[1]);
+            if (logits) *reinterpret_cast<float2 *>(logits + o) = make_float2(l[0], l[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t][0] = acc_next[t][0]; acc[t][1] = acc_next[t][1]; }
         oldh = nexth;
         __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
     }
@@ -1047,9 +1269,11 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
         finish_stats(partials, stats, metrics4, nt8, batch, st);
         return vv_launch_status();
     }
-    const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "box": override the batch heuristic (tests)
+    const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "sweepp" / "box": override the batch heuristic (tests)
     const bool sweep = dtype == VV_BF16 && side >= 8 &&
                        (force ? force[0] == 's' : (long)batch * ntile >= 128);   // enough workgroups to fill the chip
+    // "sweep" = the form with the w direction summed inside the MFMA (round 3); "sweepp" = the form that publishes P[halo cell][64 taps]
+    const bool form_p = force && !strcmp(force, "sweepp");
     if (sweep) {
         static const bool attr = [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&final_bce_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
@@ -1062,10 +1286,16 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
         if (per < 1) return VV_ERR_SHAPE;
         for (int b0 = 0; b0 < batch; b0 += per) {
             const int nbt = batch - b0 < per ? batch - b0 : per;
-            VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * nbt), dim3(256), SW_LDS, st,
-                      reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per), w_keras, target + (size_t)b0 * vox,
-                      probs ? probs + (size_t)b0 * vox : nullptr, logits ? logits + (size_t)b0 * vox : nullptr, partials + (size_t)b0 * ntile * 4,
-                      vv_log2(side), (unsigned)((size_t)nbt * in_per), gamma, epsilon);
+            if (form_p)
+                VV_LAUNCH(final_bce_sweep_kernel, dim3(ntile * nbt), dim3(256), SW_LDS, st,
+                          reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per), w_keras, target + (size_t)b0 * vox,
+                          probs ? probs + (size_t)b0 * vox : nullptr, logits ? logits + (size_t)b0 * vox : nullptr, partials + (size_t)b0 * ntile * 4,
+                          vv_log2(side), (unsigned)((size_t)nbt * in_per), gamma, epsilon);
+            else
+                VV_LAUNCH(final_bce_sweepw_kernel, dim3(ntile * nbt), dim3(256), SWW_LDS, st,
+                          reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per), w_keras, target + (size_t)b0 * vox,
+                          probs ? probs + (size_t)b0 * vox : nullptr, logits ? logits + (size_t)b0 * vox : nullptr, partials + (size_t)b0 * ntile * 4,
+                          vv_log2(side), (unsigned)((size_t)nbt * in_per), gamma, epsilon);
         }
         finish_stats(partials, stats, metrics4, ntile, batch, st);
         return vv_launch_status();

@@ -264,11 +264,12 @@ def test_conv3d_first(L, dtname, B, D):
 
 
 @pytest.mark.parametrize('dtname', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,side,form', [(2, 16, 'box'), (3, 4, 'box'), (1, 8, 'box'), (2, 16, 'sweep'), (3, 8, 'sweep'), (1, 32, 'sweep')])
+@pytest.mark.parametrize('B,side,form', [(2, 16, 'box'), (3, 4, 'box'), (1, 8, 'box'), (2, 16, 'sweep'), (3, 8, 'sweep'), (1, 32, 'sweep'),
+                                         (2, 16, 'sweepp'), (3, 8, 'sweepp')])
 def test_convT3d_final_bce(L, dtname, B, side, form, monkeypatch):
-    # bf16 has two kernels: 'box' (4^3 cells + halo per workgroup, small batches) and 'sweep' (8x8 tile swept through
-    # the depth, large batches); VV_FINAL_BCE overrides the batch heuristic so both are checked at test sizes
-    if dtname == 'f32' and form == 'sweep':
+    # bf16 has three kernels: 'box' (4^3 cells + halo per workgroup, small batches), 'sweep' (8x8 tile swept through the depth with the w
+    # direction summed inside the MFMA, large batches) and 'sweepp' (the sweep form that publishes P[cell][64 taps], kept for reference); VV_FINAL_BCE overrides the batch heuristic so both are checked at test sizes
+    if dtname == 'f32' and form.startswith('sweep'):
         pytest.skip('sweep form is bf16 only')
     monkeypatch.setenv('VV_FINAL_BCE', form)
     rng = np.random.default_rng(side)
@@ -759,8 +760,8 @@ def test_widest_layers_full_batch_forms_agree(L, monkeypatch):
 
 def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
     """B = 256 (BASELINE configs[1]: several items / steps per persistent workgroup, two workgroups per CU): the plane form of the
-    first layer equals its gather form bit for bit, and the depth-sweep form of the last layer equals the 4^3-box form (logits to
-    1e-5, loss sums to float32 summation error) and the float64 definition of the four loss sums -- run twice (a race in a
+    first layer equals its gather form bit for bit, and the depth-sweep forms of the last layer equal the 4^3-box form (logits to
+    1e-5, loss sums to float32 summation error) and the float64 definition of the four loss sums on their own logits -- run twice (a race in a
     look-ahead load showed up only here: wrong logits in the last output plane, different from run to run)."""
     B = 256
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -811,16 +812,31 @@ def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
     monkeypatch.setenv('VV_FINAL_BCE', 'box')
     lb, sb = d5()
     monkeypatch.delenv('VV_FINAL_BCE')
-    l64, t64 = lb.double().view(B, -1), tgt.double().view(B, -1)
-    q = torch.sigmoid(l64).clamp(1e-7, 1 - 1e-7)
-    yh = (l64 >= 0).double()
-    ref = torch.stack([-(0.6 * t64 * q.log() + 0.4 * (1 - t64) * (1 - q).log()).sum(1), (t64 * yh).sum(1), ((1 - t64) * yh).sum(1),
-                       (t64 * (1 - yh)).sum(1)], 1)
+    t64 = tgt.double().view(B, -1)
+
+    def sums(logit):                                   # the float64 definition of the four sums on a given set of logits
+        l64 = logit.double().view(B, -1)
+        q = torch.sigmoid(l64).clamp(1e-7, 1 - 1e-7)
+        yh = (l64 >= 0).double()
+        return torch.stack([-(0.6 * t64 * q.log() + 0.4 * (1 - t64) * (1 - q).log()).sum(1), (t64 * yh).sum(1), ((1 - t64) * yh).sum(1),
+                            (t64 * (1 - yh)).sum(1)], 1)
+    ref_box = sums(lb)
+    # The sweep form sums the two w terms of an output inside the MFMA (K = 128) and the h / d terms afterwards, the box form all
+    # eight in tap order: the logits agree to float32 rounding (1e-5), so an occupancy decision may differ only where the logit is
+    # inside that band -- the counts are exact against the sweep form's OWN logits, and within the band population of the box form's.
+    band = (lb.double().view(B, -1).abs() <= 1e-5).double().sum(1)
     for lg, st in runs:
         assert (lg - lb).abs().max().item() <= 1e-5
         assert torch.equal(lg, runs[0][0])
-        d = (st.double() - ref).abs().max(0).values
+        d = (st.double() - sums(lg)).abs().max(0).values
         assert d[0].item() <= 1e-2 and d[1:].max().item() == 0.0, d.tolist()     # loss sum ~2e4 per sample; the counts are exact
+        assert bool(((st.double() - ref_box)[:, 1:].abs().sum(1) <= 2 * band).all())
+    monkeypatch.setenv('VV_FINAL_BCE', 'sweepp')       # the form that publishes P[halo cell][64 taps] (tap order, as the box form)
+    lp, sp_ = d5()
+    monkeypatch.delenv('VV_FINAL_BCE')
+    assert (lp - lb).abs().max().item() <= 1e-5
+    d = (sp_.double() - sums(lp)).abs().max(0).values
+    assert d[0].item() <= 1e-2 and d[1:].max().item() == 0.0, d.tolist()
 
 
 @pytest.mark.skipif(F8 is None, reason='torch.float8_e4m3fn not available')
