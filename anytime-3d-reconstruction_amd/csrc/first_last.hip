@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
         const int zh = row / 10, zw = row - zh * 10;
         const int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
         const bool ok = row < SW_ROWS && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
-        const int g = (lane & 7) ^ ((row >> 1) & 7);
+        const int g = (lane & 7) ^ (zw & 7);             // slot key zw & 7: conflict-free for the 16x16x32 operand reads of centre / left / right cells (d5w_swz.py)
         sv[i] = ok ? (unsigned)(((((b << li) << li) + ih) << li) + iw) * (FB_CIN * 2) + g * 16 : 0xFFFFFFF0u;
         sdst[i] = piece < 13 ? (unsigned)(piece * 1024) : (unsigned)(SW_NX * SW_XB);     // surplus pieces: the sink (ring-slot independent)
     }
@@ -552,11 +552,15 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) xo[s3][hf] = (unsigned)fm_lds_off(rowC + (s3 == 0 ? 0 : s3 == 1 ? -1 : 1), hf * 4 + kq);
+        for (int hf = 0; hf < 2; ++hf) {
+            const int sh = s3 == 0 ? 0 : s3 == 1 ? -1 : 1, zwc = 1 + (c16 & 7) + sh;
+            xo[s3][hf] = (unsigned)((rowC + sh) * 128 + (((hf * 4 + kq) ^ (zwc & 7)) << 4));
+        }
     // Q row of a centre cell pr = zh * 8 + (zw - 1): 16 granules of 8 B = (pw 0, pw 1) of n = td * 4 + th, granule g stored at g ^ key,
-    // key = ((zw - 1) >> 1) << 1 | (zh & 1) << 3: the 32 lanes of a ds_read_b64 pass (8 columns x 2 row parities x 2 ph) hit 32 different
-    // granule positions of the two bank halves (row parity = column parity picks the half; bit 0 of g = bit 0 of th = 1 - ph)
-    auto qkey = [](int pr) { return (((pr & 7) >> 1) << 1) | (((pr >> 3) & 1) << 3); };
+    // key = ((zh + zw - 1) & 7) << 1 (bit 0 clear: the th pair of a 16-byte store stays adjacent): every ds_write_b128 lane group of the
+    // publish and both 32-lane passes of every ds_read_b64 of the gather are conflict-free (profiles/microbench/d5w_swz.py: exhaustive over
+    // linear keys under the guide's lane-group / bank model; the first key tried was 2-way on the stores)
+    auto qkey = [](int pr) { return (((pr & 7) + (pr >> 3)) & 7) << 1; };
 
     // gather role: s = od parity slot, ohh = output row inside the tile, mw = cell column (both pw per lane)
     const int mw = tid & 7, ohh = (tid >> 3) & 15, sl = tid >> 7;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
             acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < ntl) {
-                const char *Xt = Xd + t * (80 * 128);             // tile 4 = tile 0 + 8 halo rows of 10 cells: same slot keys ((row >> 1) + 40)
+                const char *Xt = Xd + t * (80 * 128);             // tile 4 = tile 0 + 8 halo rows of 10 cells: same zw, same slot keys
                 uint4 fc[2], fl[2], fr2[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
