@@ -672,11 +672,15 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
         if (ovalid) {
             const float l[2] = {l0, l1}, yy[2] = {y.x, y.y};
             float p[2];
+            // Occupancy targets are 0 or 1: then exactly one of the two logarithms of binary_loss has a non-zero factor, and the other
+            // term is +-0 -- one v_log_f32 per voxel instead of two, the same sum.  Any other target value in the wave takes the general form.
+            const bool soft = __builtin_amdgcn_ballot_w64((yy[0] != 0.f && yy[0] != 1.f) || (yy[1] != 0.f && yy[1] != 1.f)) != 0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 p[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-l[e]));
                 const float q = fminf(fmaxf(p[e], epsilon), hi);
-                bce -= gamma * yy[e] * __logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * __logf(1.0f - q);
+                if (soft) bce -= gamma * yy[e] * __logf(q) + (1.0f - gamma) * (1.0f - yy[e]) * __logf(1.0f - q);
+                else bce -= (yy[e] != 0.f ? gamma : 1.0f - gamma) * __logf(yy[e] != 0.f ? q : 1.0f - q);
                 const float yh = l[e] >= 0.f ? 1.f : 0.f;
                 tp += yy[e] * yh; fp += (1.f - yy[e]) * yh; fn += yy[e] * (1.f - yh);
             }
