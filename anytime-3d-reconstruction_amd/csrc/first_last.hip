@@ -499,10 +499,10 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
 
     const u32x4 rs = vv_make_rsrc(x, x_bytes);
     const unsigned ldsx = (unsigned)(unsigned long long)(lptr_t)Xs;
-    // plane d -> ring slot d % 3: 13 pieces of 8 rows; every wave issues 4 (the 3 surplus ones go to the sink so that the
+    // plane d -> ring slot d % 2: 13 pieces of 8 rows; every wave issues 4 (the 3 surplus ones go to the sink so that the
     // vector-memory counter advances uniformly); rows >= 100, voxels outside the grid and planes outside [0, n) arrive
-    // as zeros (the virtual plane d = n closes the sweep).  The 4th MFMA row tile reads rows 96..127, i.e. 24 rows past
-    // the slot: whatever it finds there only reaches accumulator rows >= 104, which are never published.
+    // as zeros (the virtual plane d = n closes the sweep).  The operand reads stay inside rows 0 .. 99 (centre cells zw = 1 .. 8 and
+    // their left / right neighbours).
     // The lane part of a piece's source offset (sample, halo row, swizzled slot; out-of-range if the row is outside the grid
     // or past the 100 halo rows) is prepared once; the plane rides in soffset.
     unsigned sv[4], sdst[4];
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
     const int oh = 2 * h0 + ohh, ow = 2 * (w0 + mw);
     const float hi = 1.0f - epsilon;
     float bce = 0.f, tp = 0.f, fp = 0.f, fn = 0.f;
-    float lo0 = 0.f, lo1 = 0.f;                                  // td in {2,3} contributions of P_{d-1} to this step's outputs (P_{-1} = 0)
+    float lo0 = 0.f, lo1 = 0.f;                                  // td in {2,3} contributions of Q_{d-1} to this step's outputs (Q_{-1} = 0)
 
     // Q_d[n][cell][pw] for this wave's tiles: D[n][cell], weights first, K = (centre | left) / (right | centre) channels
     auto mfma_plane = [&](int sp, f32x4 (&acc)[2][2]) {           // sp = ring slot of the plane; acc[tile][pw]
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
         }
     };
 
-    // Software pipeline: step d publishes P_d (computed during step d-1) and then runs the MFMAs of plane d+1 in the same
+    // Software pipeline: step d publishes Q_d (computed during step d-1) and then runs the MFMAs of plane d+1 in the same
     // instruction stream as the gather / loss math of plane d (matrix pipe under the VALU and LDS work).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // plane 0
     __syncthreads();                                             // ... for every wave
@@ -609,9 +609,6 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
     for (int k = 1; k <= SW_DEPTH; ++k) stage(k, k);
     __syncthreads();                                             // slot 0 may be refilled from the first step on
 
-    // (Unrolling this loop by two with the step parity as a compile-time constant -- ring slot and P buffer addresses folded
-    // into the instructions -- is worth 2 % (53.5 vs 54.7 us) in the clean kernel; with the ablation switches still compiled in
-    // it returned a low loss sum at B = 256 with exact logits and counts, which is not understood: not used.)
     int oldh = 0;                                                // ring slot of plane d
 #pragma unroll 1
     for (int d = 0; d <= n; ++d) {
@@ -628,26 +625,17 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
         const int od = 2 * d - 1 + sl;
         const bool ovalid = (unsigned)od < (unsigned)n2;
         const size_t o = ((((((size_t)b << lo) + (ovalid ? od : 0)) << lo) + oh) << lo) + ow;
-        // The target pair is loaded by inline asm so that its wait can be counted: the vector-memory counter retires in
-        // order, and a compiler-placed wait for this load would be vmcnt(0), i.e. it would also wait for the 4 pieces of
-        // plane d+2 issued right after it -- the look-ahead.  In flight, oldest first:
-        //   [plane d+1 x4][stores d-1] [y d][plane d+2 x4]
-        // so "all but the newest 5" covers plane d+1 whatever the number of stores (more stores only wait for more).
-        // An asm output is a READY value to the compiler: nothing in the language stops it from copying y or re-using its
-        // registers while the load is in flight.  tests/test_isa_lint.py checks on the generated code that no instruction
-        // names the pair between this load and the counted wait below that lands it ("+v"(y)); round 2's dead ends came from
-        // exactly that (a look-ahead load whose last instance was DEAD: its registers went to the logit accumulators of the
-        // last plane while it was in flight -- DESIGN.md section 4d).  The two compiler-managed alternatives were built in round 3
-        // and are worse: a plain load of the noalias argument is moved by the compiler across the asm statements into the
-        // `ovalid` branch (behind the counted wait, whose count then no longer holds: wrong logits), a volatile load becomes a
-        // system-scope flat load with an immediate vmcnt(0).
+        // The target pair is loaded by inline asm so that its wait can be counted (see final_bce_sweep_kernel for the history and the
+        // compiler-managed forms that fail).  In flight, oldest first: [plane d+1 x4][stores d-1] [y d][plane d+2 x4]: "all but the newest
+        // 5" covers plane d+1 whatever the number of stores.  tests/test_isa_lint.py checks on the generated code that no instruction
+        // names the pair between this load and the counted wait below that lands it ("+v"(y)).
         float2 y;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(y) : "v"(target + o) : "memory");
         stage(d + 1 + SW_DEPTH, oldh);
         // depth 1: [plane d+1 x4][stores d-1][y d][plane d+2 x4] -> all but the newest 5.  depth 2: plane d+1 is followed by
         // stores d-2 (0..2), y d-1, plane d+2 x4, stores d-1 (0..2), y d, plane d+3 x4 = 10..14 operations -> all but the newest 10
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW_DEPTH == 1 ? 5 : 10) : "memory");         // plane d+1 has landed
-        __syncthreads();                                         // ... for every wave; P_d is published
+        __syncthreads();                                         // ... for every wave; Q_d is published
 
         f32x4 acc_next[2][2];
         const int nexth = oldh + 1 == SW_NX ? 0 : oldh + 1;      // ring slot of plane d+1
@@ -690,7 +678,7 @@ __global__ __launch_bounds__(256, 4) void final_bce_sweepw_kernel(const __bf16 *
 #pragma unroll
         for (int t = 0; t < 2; ++t) { acc[t][0] = acc_next[t][0]; acc[t][1] = acc_next[t][1]; }
         oldh = nexth;
-        __syncthreads();      // every gather of P_d / P_{d-1} and every read of plane d+1 is done: publish d+1, refill its slot
+        __syncthreads();      // every gather of Q_d and every read of plane d+1 is done: publish d+1, refill its slot
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the last (all-zero) look-ahead planes
     bce = vv_wave_sum(bce); tp = vv_wave_sum(tp); fp = vv_wave_sum(fp); fn = vv_wave_sum(fn);
