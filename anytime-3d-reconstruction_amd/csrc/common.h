@@ -49,9 +49,17 @@ static inline int vv_log2(int v) {
 // Buffer descriptors carry 32-bit offsets: a launch covers at most 2 GiB of its largest per-sample-indexed tensor; larger batches
 // go out as several launches over sample ranges (samples are independent).  VV_CHUNK_SAMPLES caps the range (tests).
 #include <stdlib.h>
+// Test hooks (kernel-form overrides for A/B tests and microbenchmarks) exist only in the build with -DVV_TEST_HOOKS
+// (lib/libvoxvae_hooks.so, loaded by tests that set one of the VV_* variables); the release library reads no environment
+// variable at all: vv_hook("...") is a null pointer there and the name does not reach the binary.
+#ifdef VV_TEST_HOOKS
+static inline const char *vv_hook(const char *name) { return getenv(name); }
+#else
+#define vv_hook(name) (static_cast<const char *>(nullptr))
+#endif
 static inline int vv_chunk_samples(size_t sample_bytes, int batch) {
     size_t per = sample_bytes ? 0x7FFFFFFFull / sample_bytes : (size_t)batch;
-    if (const char *e = getenv("VV_CHUNK_SAMPLES")) {
+    if (const char *e = vv_hook("VV_CHUNK_SAMPLES")) {
         const long v = atol(e);
         if (v > 0 && (size_t)v < per) per = (size_t)v;
     }

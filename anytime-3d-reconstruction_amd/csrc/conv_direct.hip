@@ -484,7 +484,7 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
         return true;
     }();
     (void)attr;
-    const char *se = getenv("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    const char *se = vv_hook("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
     const bool s16 = !se || atoi(se) != 32;
     const size_t in_per = (size_t)side * side * side * cin * 2, out_per = (size_t)so * so * so * cout * (out_dtype == VV_FP8 ? 1 : 2);
     const int per = vv_chunk_samples(in_per, batch);

@@ -289,7 +289,7 @@ VV_EXPORT int vv_convT3d_k4s2_direct_fwd(const void *x, const void *w_frag, cons
     if (!vv_aligned16(x) || !vv_aligned16(w_frag) || !vv_aligned16(y)) return VV_ERR_ALIGN;
     // variants: "2" = 2x4x8 cells, 4 waves x 2 parities, 2 workgroups / CU; "4" = 4x4x8 cells, 4 waves x 2 parities;
     // "8" = 4x4x8 cells, 8 waves x 1 parity (each weight fragment feeds 4 MFMAs, 2 waves / SIMD)
-    const char *sel_env = getenv("VV_DIRECT_MT");                       // read per call so that tests can cover every variant
+    const char *sel_env = vv_hook("VV_DIRECT_MT");                       // read per call so that tests can cover every variant
     const int sel = sel_env ? atoi(sel_env) : 8;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto launch = [&](auto mt_c, auto nw_c) {

@@ -471,11 +471,11 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
     // algorithmic bytes.
     int ps = 1;
     while (ps < 8 && (long)batch * ps < 256) ps *= 2;
-    if (const char *e = getenv("VV_CTW_PS")) {
+    if (const char *e = vv_hook("VV_CTW_PS")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
     }
-    const char *se = getenv("VV_CTW_SHAPE");        // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    const char *se = vv_hook("VV_CTW_SHAPE");        // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
     const bool shape16 = !se || atoi(se) != 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto launch = [&](auto act_c) {

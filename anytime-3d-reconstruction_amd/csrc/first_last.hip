@@ -1265,7 +1265,7 @@ int final_bce_impl(const void *x, const float *w_keras, const float *target, flo
         finish_stats(partials, stats, metrics4, nt8, batch, st);
         return vv_launch_status();
     }
-    const char *force = getenv("VV_FINAL_BCE");                  // "sweep" / "sweepp" / "box": override the batch heuristic (tests)
+    const char *force = vv_hook("VV_FINAL_BCE");                  // "sweep" / "sweepp" / "box": override the batch heuristic (tests)
     const bool sweep = dtype == VV_BF16 && side >= 8 &&
                        (force ? force[0] == 's' : (long)batch * ntile >= 128);   // enough workgroups to fill the chip
     // "sweep" = the form with the w direction summed inside the MFMA (round 3); "sweepp" = the form that publishes P[halo cell][64 taps]
@@ -1313,16 +1313,16 @@ int vv_first_conv_bf16_launch(const float *x, const void *w_packed, const float 
                               int side, int act, void *stream, int out_fp8) {
     const int li = vv_log2(side);
     if (out_fp8 && !(side >= 32 && side <= 256)) return VV_ERR_DTYPE;      // only the plane-form kernel stores e4m3fn
-    if (side >= 32 && side <= 256 && (out_fp8 || !getenv("VV_FIRSTCONV_GATHER"))) {
+    if (side >= 32 && side <= 256 && (out_fp8 || !vv_hook("VV_FIRSTCONV_GATHER"))) {
         const int ow = side / 2, oh = 256 / ow, r = 2 * oh + 2, pd = side / 2 + 2;
         const long nitems = (long)batch * ow * (ow / oh);
         const size_t tile_b = ((size_t)4 * r * pd * 4 + 15) & ~(size_t)15;
         const size_t lds = tile_b + (out_fp8 ? (size_t)256 * (64 * 2) : tile_b) + 128 * sizeof(float) + 8 * 64 * 16;
         const int nslots = 4 * r * (side / 4), ni = (nslots + 255) / 256;
-        static const long envwg = getenv("VV_FIRSTCONV_WGS") ? atol(getenv("VV_FIRSTCONV_WGS")) : 0;
+        static const long envwg = vv_hook("VV_FIRSTCONV_WGS") ? atol(vv_hook("VV_FIRSTCONV_WGS")) : 0;
         // D = 32 / 64 and batches that give every workgroup a chain of >= 2 consecutive output planes: the chained kernel, FOUR persistent
         // workgroups per CU (D = 32, batch 256: 4,096 items = 1,024 x 4); its input offsets are 32-bit (< 2 GiB of input per launch)
-        const bool nochain = getenv("VV_FIRSTCONV_NOCHAIN") != nullptr;      // test hook: the plane form at every batch
+        const bool nochain = vv_hook("VV_FIRSTCONV_NOCHAIN") != nullptr;      // test hook: the plane form at every batch
         if ((side == 32 || side == 64) && !nochain && (size_t)batch * side * side * side * sizeof(float) < 0x7FFFFFFFull) {
             const long maxwg4 = envwg > 0 ? envwg : 256 * 4;
             const int ipw4 = (int)((nitems + maxwg4 - 1) / maxwg4);

@@ -658,16 +658,16 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
     const int bk = dtype == VV_BF16 ? 64 : (dtype == VV_FP8 ? 128 : 32);
     const int nchunks = (K + bk - 1) / bk;
     const long tiles = (long)((M + p.bm - 1) / p.bm) * ((N + p.bn - 1) / p.bn) * p.nparity;
-    static const long target = getenv("VV_SPLIT_TARGET") ? atol(getenv("VV_SPLIT_TARGET")) : 512;
+    static const long target = vv_hook("VV_SPLIT_TARGET") ? atol(vv_hook("VV_SPLIT_TARGET")) : 512;
     int split = 1;
     // at least 8 chunks per share -- 4 when the tile grid is a handful of workgroups (the Dense-shaped layers at batch
     // 256: 2 tiles x K = 4096 ran as 8 workgroups of 16 dependent chunks, a latency chain of 18 us)
-    static const int min_chunks_small = getenv("VV_SPLIT_MINCHUNKS") ? atoi(getenv("VV_SPLIT_MINCHUNKS")) : 4;
+    static const int min_chunks_small = vv_hook("VV_SPLIT_MINCHUNKS") ? atoi(vv_hook("VV_SPLIT_MINCHUNKS")) : 4;
     const int min_chunks = tiles <= 8 ? min_chunks_small : 8;
     while (tiles * split < target && split * 2 <= nchunks / min_chunks && split < 64) split *= 2;
     // The first factor of two is taken INSIDE the workgroup (two 4-wave halves on alternate chunks, accumulators handed
     // over through LDS): same waves per CU, half the slabs -- or none, and then no reduce pass at all.
-    static const bool no_kh = getenv("VV_NO_KHALVES") != nullptr;
+    static const bool no_kh = vv_hook("VV_NO_KHALVES") != nullptr;
     p.kh = 1;
     if (split >= 2 && mode != MODE_FIRST && !no_kh) { p.kh = 2; split /= 2; }
     p.cps = (nchunks + split - 1) / split;
@@ -678,8 +678,8 @@ Plan make_plan(int mode, int M, int N, int K, int dtype) {
 
 // Position-major rows pay off where a large share of the taps is padding (small grids) and the batch fills tiles.
 bool use_pos_major(int mode, int din, int batch) {
-    static const int conv_max = getenv("VV_POSMAJOR_CONV_SIDE") ? atoi(getenv("VV_POSMAJOR_CONV_SIDE")) : 8;
-    static const int convT_max = getenv("VV_POSMAJOR_CONVT_SIDE") ? atoi(getenv("VV_POSMAJOR_CONVT_SIDE")) : 4;
+    static const int conv_max = vv_hook("VV_POSMAJOR_CONV_SIDE") ? atoi(vv_hook("VV_POSMAJOR_CONV_SIDE")) : 8;
+    static const int convT_max = vv_hook("VV_POSMAJOR_CONVT_SIDE") ? atoi(vv_hook("VV_POSMAJOR_CONVT_SIDE")) : 4;
     if (batch < 32) return false;
     if (mode == MODE_CONV) return din <= conv_max;
     if (mode == MODE_CONVT) return din <= convT_max;
@@ -704,7 +704,7 @@ template <typename T, int MODE>
 int launch_t(const IgemmArgs &a, const Plan &p, hipStream_t st) {
     const int tiles = ((a.M + p.bm - 1) / p.bm) * ((a.N + p.bn - 1) / p.bn);
     dim3 grid(tiles * p.split * p.nparity);
-    static const int stages_env = getenv("VV_STAGES") ? atoi(getenv("VV_STAGES")) : 2;
+    static const int stages_env = vv_hook("VV_STAGES") ? atoi(vv_hook("VV_STAGES")) : 2;
     const int stages = (MODE == MODE_FIRST || sizeof(T) == 4) ? 2 : stages_env;   // deep ring: bf16 LDS-DMA modes only
     if (p.kh == 2) {
         if constexpr (MODE != MODE_FIRST) {
@@ -863,7 +863,7 @@ VV_EXPORT int vv_conv3d_first_fwd_io(const float *x, const void *w_packed, const
         return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream, 1);
     }
     if (out_dtype != dtype) return VV_ERR_DTYPE;
-    if (dtype == VV_BF16 && cout == 64 && x && w_packed && y && vv_aligned16(y) && vv_aligned16(w_packed) && !getenv("VV_NO_FIRSTCONV"))
+    if (dtype == VV_BF16 && cout == 64 && x && w_packed && y && vv_aligned16(y) && vv_aligned16(w_packed) && !vv_hook("VV_NO_FIRSTCONV"))
         return vv_first_conv_bf16_launch(x, w_packed, scale, shift, y, batch, side, act, stream, 0);
     return run_igemm(MODE_FIRST, x, w_packed, scale, shift, y, batch * o * o * o, cout, 64, side, 1, act, dtype, dtype, nullptr,
                      0, stream, batch);

@@ -293,7 +293,7 @@ struct LtPlan { int kslice, nslice, nq; size_t ws; };
 
 LtPlan lt_plan(int batch, int K5, int E, int n1) {
     LtPlan p;
-    static const int ks_env = getenv("VV_LT_KSLICE") ? atoi(getenv("VV_LT_KSLICE")) : 0;
+    static const int ks_env = vv_hook("VV_LT_KSLICE") ? atoi(vv_hook("VV_LT_KSLICE")) : 0;
     int ks = (K5 + 31) / 32;                               // at most 32 slices
     if (ks_env > ks) ks = ks_env;
     ks = ((ks + LT_KS - 1) / LT_KS) * LT_KS;

@@ -363,7 +363,7 @@ void pg_plan(PgArgs &a, int batch, int cin, int cout) {
         chunks[p] = pg_axis<MODE>(od).cnt * pg_axis<MODE>(oh).cnt * pg_axis<MODE>(ow).cnt * NC;
         total += chunks[p];
     }
-    static const int target_env = getenv("VV_PG_TARGET") ? atoi(getenv("VV_PG_TARGET")) : 0;
+    static const int target_env = vv_hook("VV_PG_TARGET") ? atoi(vv_hook("VV_PG_TARGET")) : 0;
     long avg = (total * a.ntn * a.mtiles + 255) / 256;
     int target = (int)((avg + NC - 1) / NC) * NC;
     if (target < 8) target = 8;

@@ -1001,7 +1001,7 @@ WgradPlan wgrad_plan_bf16(long R, int M, int N) {
 }
 
 bool wgrad_bf16_ok(const void *A, const void *G, long R, int M, int N, int lda, int cin, int amode, size_t a_elems) {
-    if (getenv("VV_WGRAD_F32")) return false;
+    if (vv_hook("VV_WGRAD_F32")) return false;
     if (M % 32 || N % 32) return false;
     if (amode == 0 && lda % 8) return false;
     if (amode == 1 && cin % 64) return false;
@@ -1093,7 +1093,7 @@ VV_EXPORT int vv_wgrad_conv_k4s2(const void *src, const void *g, float *dw, int 
                       (unsigned)(src_elems * 2), (unsigned)((size_t)rows * cout * 2)};
         return launch_wgrad_bf16<1>(wb, pb, dw, st);
     }
-    if (cin == 1 && side >= 4 && g_dtype == VV_BF16 && cout % 32 == 0 && (size_t)rows * cout * 2 < 0xFFFFFFF0ull && vv_aligned16(g) && !getenv("VV_WGRAD_F32")) {
+    if (cin == 1 && side >= 4 && g_dtype == VV_BF16 && cout % 32 == 0 && (size_t)rows * cout * 2 < 0xFFFFFFF0ull && vv_aligned16(g) && !vv_hook("VV_WGRAD_F32")) {
         // single input channel: the 64-tap rows are built from the float32 grid inside the bf16 kernel's staging
         const WgradPlan pb = wgrad_plan_bf16(rows, 64, cout);
         WgradBArgs wb{src, g, reinterpret_cast<float *>(workspace), rows, 64, cout, 0, vv_log2(side), 1, pb.rps, 0u,

@@ -258,7 +258,7 @@ void wg_phase_launch(const WgPhaseArgs &a, int kinds, hipStream_t st) {
 }  // namespace
 
 bool vv_wgrad_phase_ok(const void *src, const void *g, int batch, int side, int cin, int cout) {
-    if (getenv("VV_NO_WGRAD_PHASE") || getenv("VV_WGRAD_F32")) return false;
+    if (vv_hook("VV_NO_WGRAD_PHASE") || vv_hook("VV_WGRAD_F32")) return false;
     const int S = side / 2;
     if (S != 4 && S != 8 && S != 16) return false;
     if (cin % 64 || cout % 128) return false;

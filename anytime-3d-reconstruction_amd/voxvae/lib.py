@@ -11,6 +11,14 @@ import torch  # noqa: F401  -- FIRST: libvoxvae must bind to the HIP runtime tor
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae.so')
+# The release library reads no environment variable.  The kernel-form overrides of the A/B tests and microbenchmarks live in a second
+# build of the same sources (lib/libvoxvae_hooks.so, -DVV_TEST_HOOKS); a process that sets VOXVAE_TEST_HOOKS=1 (tests/conftest.py, the
+# scripts under profiles/microbench/) has its calls routed there WHILE one of the hook variables below is set, and to the release
+# library otherwise -- so everything that does not ask for an override still runs the product.
+HOOKS_LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae_hooks.so')
+HOOK_VARS = ('VV_CD_SHAPE', 'VV_DIRECT_MT', 'VV_LT_KSLICE', 'VV_SPLIT_TARGET', 'VV_SPLIT_MINCHUNKS', 'VV_NO_KHALVES', 'VV_POSMAJOR_CONV_SIDE',
+             'VV_POSMAJOR_CONVT_SIDE', 'VV_STAGES', 'VV_NO_FIRSTCONV', 'VV_WGRAD_F32', 'VV_PG_TARGET', 'VV_CTW_PS', 'VV_CTW_SHAPE',
+             'VV_NO_WGRAD_PHASE', 'VV_FINAL_BCE', 'VV_FIRSTCONV_GATHER', 'VV_FIRSTCONV_WGS', 'VV_FIRSTCONV_NOCHAIN', 'VV_CHUNK_SAMPLES')
 
 VV_F32, VV_BF16, VV_FP8 = 0, 1, 2
 ACT = {None: 0, 'None': 0, 'linear': 0, 'elu': 1, 'relu': 2, 'lrelu': 3}
@@ -109,25 +117,42 @@ class VoxVaeError(RuntimeError):
 
 
 _lib = None
+_hooks_lib = None
+
+
+def _open(path, hooks):
+    if not os.path.exists(path):
+        raise VoxVaeError('HIP library missing: %s (run `python __graft_entry__.py` / voxvae/build.py); '
+                          'there is no CPU fallback' % path)
+    # a library built from other sources than the ones in the tree is refused (content hash written by voxvae/build.py):
+    # a stale .so would otherwise run silently after a checkout that resets mtimes
+    from . import build as _build
+    if os.path.isdir(_build.CSRC) and os.path.exists(path + '.srchash') and not _build.is_current(hooks):
+        raise VoxVaeError('%s is stale: csrc/ or include/voxvae.h changed since it was built (run `python __graft_entry__.py`)' % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def hooks_requested():
+    """True while this process opted into the test-hook build AND one of its variables is set."""
+    env = os.environ
+    return env.get('VOXVAE_TEST_HOOKS') == '1' and any(v in env for v in HOOK_VARS)
 
 
 def load():
-    """Loads the library (once).  Raises VoxVaeError when it has not been built -- by design."""
-    global _lib
+    """The library the next call goes to (loaded once each): the release build, or -- only in a process that set
+    VOXVAE_TEST_HOOKS=1, and only while a hook variable is set -- the -DVV_TEST_HOOKS build.  Raises VoxVaeError when the
+    library has not been built -- by design."""
+    global _lib, _hooks_lib
+    if hooks_requested():
+        if _hooks_lib is None:
+            _hooks_lib = _open(HOOKS_LIB_PATH, True)
+        return _hooks_lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise VoxVaeError('HIP library missing: %s (run `python __graft_entry__.py` / voxvae/build.py); '
-                              'there is no CPU fallback' % LIB_PATH)
-        # a library built from other sources than the ones in the tree is refused (content hash written by voxvae/build.py):
-        # a stale .so would otherwise run silently after a checkout that resets mtimes
-        from . import build as _build
-        if os.path.isdir(_build.CSRC) and os.path.exists(LIB_PATH + '.srchash') and not _build.is_current():
-            raise VoxVaeError('%s is stale: csrc/ or include/voxvae.h changed since it was built (run `python __graft_entry__.py`)' % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)      # AttributeError if the symbol is not exported
-            fn.restype, fn.argtypes = res, args
-        _lib = lib
+        _lib = _open(LIB_PATH, False)
     return _lib
 
 

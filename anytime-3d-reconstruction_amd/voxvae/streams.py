@@ -25,6 +25,26 @@ class StreamedEvaluator:
         self.device = torch.device(device) if device is not None else self.models[0]._device
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)] if streams > 1 else [None]
         self._next = 0
+        self._pack_event, self._pack_pending = None, set()
+
+    def _ensure_packed(self, model):
+        """Weight packing is lazy (engine.forward -> ensure_packed) and the streams share one model: whichever stream ran first
+        after a weight change would pack, and the next stream -- which only waits for the CALLER's stream -- would read images that
+        are still being written (and the repack frees the old images while other streams may still read them).  So the pack runs
+        here, on the caller's stream, after every stream has drained what it had in flight, and every stream's next step waits for
+        it (an event: the caller may issue its next submit from another stream)."""
+        enc, dec = model._enc_eng, model._dec_eng
+        if not (enc._dirty or dec._dirty or not enc._folded or not dec._folded):
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            if s is not None:
+                cur.wait_stream(s)
+        enc.ensure_packed()
+        dec.ensure_packed()
+        self._pack_event = torch.cuda.Event()
+        self._pack_event.record(cur)
+        self._pack_pending = set(id(s) for s in self.streams if s is not None)
 
     def submit(self, x, y, eps=None):
         """Enqueue model.eval_forward_device(x, y, eps) on the next stream; x, y, eps must be ready on the caller's current
@@ -33,9 +53,13 @@ class StreamedEvaluator:
         i = self._next
         self._next = (i + 1) % len(self.models)
         s = self.streams[i]
+        self._ensure_packed(self.models[i])
         if s is None:
             return self.models[i].eval_forward_device(x, y, eps)
         s.wait_stream(torch.cuda.current_stream(self.device))
+        if self._pack_event is not None and id(s) in self._pack_pending:
+            s.wait_event(self._pack_event)
+            self._pack_pending.discard(id(s))
         for t in (x, y, eps):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(s)                 # the caller may free its inputs before this stream has read them

@@ -209,7 +209,9 @@ def trained_parity(a, dev, build_model):
     from voxvae import synthetic as syn
     from voxvae import trained as tr
     t0 = time.perf_counter()
-    cfg_t, ep_t, dp_t, info = tr.train_operating_point(voxel=a.voxel, latent=a.latent, device=dev)
+    # 64^3 (config 5's geometry): the recipe of tests/test_gpu_trained.py::trained64 -- bf16 mixed-precision fit at batch 32
+    fit_kw = dict(batch=32, pool=256, dtype='bf16', max_steps=3000) if a.voxel >= 64 else {}
+    cfg_t, ep_t, dp_t, info = tr.train_operating_point(voxel=a.voxel, latent=a.latent, device=dev, **fit_kw)
     t_fit = time.perf_counter() - t0
     n = 256
     xh = np.concatenate([syn.make_voxels(256, a.voxel, seed=4321)[:192], syn.make_voxels(64, a.voxel, seed=777)], axis=0)
@@ -217,19 +219,26 @@ def trained_parity(a, dev, build_model):
     ref = co.vae_eval_forward(cfg_t, ep_t, dp_t, xh, xh, epsh)
     iou_c = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
     x, eps = torch.from_numpy(xh).to(dev), torch.from_numpy(epsh).to(dev)
-    out = {'fit_steps': info['steps'], 'fit_seconds': t_fit, 'fit_dtype': 'f32', 'reached': bool(info['reached']), 'samples': n,
+    out = {'fit_steps': info['steps'], 'fit_seconds': t_fit, 'fit_dtype': info['fit_dtype'], 'reached': bool(info['reached']), 'samples': n,
            'iou_ref': float(iou_c.mean()), 'max_abs_ref_logit': float(np.abs(ref['logits']).max()),
            'fraction_of_voxels_beyond_the_clip': float(np.mean(np.abs(ref['logits']) > 15.94)),
-           'what': '32^3 VAE fitted by fit() on 256 seeded synthetic shapes; 192 seen + 64 unseen shapes evaluated; oracle = fp32 C restatement'}
+           'what': '%d^3 VAE fitted by fit() on 256 seeded synthetic shapes; 192 seen + 64 unseen shapes evaluated; oracle = fp32 C restatement' % a.voxel}
     for dt in dict.fromkeys([a.dtype, 'f32']):
         voxvae.set_default_dtype(dt)
         m = build_model(True, cfg_t, ep_t, dp_t)
         voxvae.set_default_dtype(a.dtype)
-        _, z_act, _ = m._encode_latent(x, eps)
-        _, lg, st_ = m._dec_eng.forward(z_act, x, want_logits=True)
-        p = parity_against(ref, lg.cpu().numpy(), st_.cpu().numpy())
-        bce_rel = float(np.max(np.abs(st_.cpu().numpy()[:, 0].astype(np.float64) - ref['bce']) / ref['bce']))
-        d = {'iou_delta': p['iou_delta'], 'max_per_sample_iou_delta': p['max_per_sample_iou_delta'], 'max_logit_err': p['max_logit_err'],
+        lgs, sts = [], []
+        for lo in range(0, n, 64):
+            _, z_act, _ = m._encode_latent(x[lo:lo + 64].contiguous(), eps[lo:lo + 64].contiguous())
+            _, lg, st_ = m._dec_eng.forward(z_act, x[lo:lo + 64].contiguous(), want_logits=True)
+            lgs.append(lg.cpu().numpy())
+            sts.append(st_.cpu().numpy())
+        lg, st_ = np.concatenate(lgs), np.concatenate(sts)
+        p = parity_against(ref, lg, st_)
+        ioug = st_[:, 1].astype(np.float64) / np.maximum(st_[:, 1:4].astype(np.float64).sum(1), 1)
+        p['iou_delta_stderr'] = float((ioug - iou_c).std(ddof=1) / np.sqrt(n))
+        bce_rel = float(np.max(np.abs(st_[:, 0].astype(np.float64) - ref['bce']) / ref['bce']))
+        d = {'iou_delta': p['iou_delta'], 'iou_delta_stderr': p['iou_delta_stderr'], 'max_per_sample_iou_delta': p['max_per_sample_iou_delta'], 'max_logit_err': p['max_logit_err'],
              'flips': p['occupancy_flips'], 'flips_outside_guard_band': p['occupancy_flips_outside_guard_band'],
              'max_abs_ref_logit_at_a_flip': p['max_abs_ref_logit_at_a_flip'], 'max_rel_bce_err_per_sample': bce_rel}
         if dt == a.dtype:
@@ -393,6 +402,7 @@ def main():
     lm = {n: v for n, v, _ in workload.layer_macs(cfg)}
     dominant, breakdown = 'D4', None
     single = None
+    pre = {'one_stream_layer_breakdown': 0, 'one_stream_rate': 0, 'schedule_preparation': 0}   # steps that run BEFORE the W warm-up steps
     if not a.no_breakdown:
         for _ in range(3):                      # weight packing, allocator growth and clock ramp happen here
             step1()
@@ -403,6 +413,7 @@ def main():
             step1()
         torch.cuda.synchronize()
         model._enc_eng.timer = model._dec_eng.timer = None
+        pre['one_stream_layer_breakdown'] = 13
         breakdown = {k: round(float(np.median([e0.elapsed_time(e1) for e0, e1 in v])), 4) for k, v in t.events.items()}
         dominant = max(breakdown, key=breakdown.get)
         if nstreams > 1:
@@ -411,6 +422,7 @@ def main():
             ti = E.LayerTimer(only=dominant)
             model._enc_eng.timer = model._dec_eng.timer = ti
             dt1 = time_steps(step1, 100, 20)
+            pre['one_stream_rate'] = 120
             model._enc_eng.timer = model._dec_eng.timer = None
             ev_ = ti.events[dominant][-100:]
             single = {'streams': 1, 'value': a.batch / dt1, 'ms_per_step': 1e3 * dt1, 'steps': 100,
@@ -428,6 +440,7 @@ def main():
         for _ in range(10 * nstreams):
             step()
         ev.synchronize()
+        pre['schedule_preparation'] = 10 * nstreams
 
     # ---- timed region
     for _ in range(a.warmup):
@@ -457,7 +470,7 @@ def main():
     # team spin-waits on every host core and would starve the launch thread
     cpu, cpu_torch, parity, f32_leg, h2d, cfg1, trained = None, None, None, None, None, None, None
     if rank == 0 and world == 1 and a.cpu_samples > 0:
-        if a.voxel == 32:
+        if a.voxel in (32, 64):
             trained = trained_parity(a, dev, build_model)
         ref, cpu = cpu_baseline(cfg, ep, dp, xh, epsh, a.cpu_samples)
         cpu_torch = cpu_baseline_torch(cfg, ep, dp, xh, epsh, ref)
@@ -573,6 +586,26 @@ def main():
             roof = roofline_of(kms)
             roof.update({'launch_ms': kms, 'launches_timed': nl, 'measured': 'HIP events on the launch stream inside the timed region'})
         roof.update({'traffic': traffic, 'traffic_stale': traffic_stale, 'traffic_source': traffic_src})
+        # the two HBM-bound ends of the path (north_star: "achieved HBM GB/s on the voxel load"): algorithmic bytes of one launch
+        # over its HIP-event duration (one batch at a time, ~5 us of event overhead included) against the 8 TB/s spec, with the
+        # counter bytes of the stamped PMC summary next to them
+        roof_hbm = None
+        if breakdown:
+            roof_hbm = {}
+            for name, abytes in (('E1', a.batch * (a.voxel ** 3 * 4 + half * cfg['encoder']['filter_num_list'][0] * es)),
+                                 ('D%d' % nlast, a.batch * (half * cfg['decoder']['filter_num_list'][-2] * es + 2 * a.voxel ** 3 * 4))):
+                if name not in breakdown or breakdown[name] <= 0:
+                    continue
+                ms = breakdown[name]
+                cb = None
+                if traffic_stale is False:
+                    cb = tj['layers'].get('D5' if name == 'D%d' % nlast else name, {}).get('hbm_bytes_per_launch')
+                roof_hbm[name] = {'algorithmic_bytes_per_launch': abytes, 'launch_ms': ms, 'achieved_GBps': abytes / (ms * 1e-3) / 1e9, 'peak_GBps': 8000.0,
+                                  'frac': abytes / (ms * 1e-3) / 8e12, 'frac_of_measured_copy_rate_6290GBps': abytes / (ms * 1e-3) / 6.29e12,
+                                  'counter_bytes_per_launch': cb, 'counter_over_algorithmic': (cb / abytes if cb else None),
+                                  'counter_source': traffic_src, 'counter_stale': traffic_stale}
+            roof_hbm['what'] = ('E1 = the voxel load (reads the float32 grid, writes the widest encoder activation); the last layer reads the widest '
+                                'decoder activation + the target and writes the probabilities; launch_ms = HIP events around the launch, one batch at a time')
         # every MFMA layer against its own algorithmic FLOPs (the table the judge recomputes from layer_ms)
         layer_frac = None
         if breakdown:
@@ -583,9 +616,14 @@ def main():
             'value': world * a.batch * a.steps / el,
             'unit': 'reconstructions/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'pre_timed_steps': dict(pre, total=sum(pre.values()), streams=nstreams,
+                                    note='steps run before the W warm-up steps: per-layer breakdown and one-batch-at-a-time rate on the caller\'s stream, '
+                                         'then 10 per stream so that every stream has its hardware queue and allocator pool; the timed region is exactly K steps'),
             'ms_per_step': 1e3 * el / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': a.dtype, 'data': 'synthetic', 'fp8_policy': a.fp8_policy if a.dtype == 'fp8' else None,
+            'fp8_weight_rounding': ('e4m3fn, per-output-channel scale, error diffusion over the taps an output sums (voxvae/engine.py:quant_fp8)'
+                                    if a.dtype == 'fp8' else None),
             'config': {'workload': 'ModelNet40 VAE getEval(missing_prob=0), %d^3 voxels, latent %d, batch %d per GPU, '
                                    'encoder+reparam/KL+decoder+BCE/TP/FP/FN (%s)' % (a.voxel, a.latent, a.batch, baseline_config_label(a)),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world,
@@ -603,6 +641,7 @@ def main():
                            'achieved_TFLOPs_per_gpu': fl_rec * a.batch * a.steps * world / el / world / 1e12,
                            'frac_of_mfma_peak': fl_rec * a.batch * a.steps / el / PEAK[a.dtype]},
             'roofline': roof,
+            'roofline_hbm': roof_hbm,
             'single_stream': single,
             'layer_ms': breakdown, 'layer_frac_of_mfma_peak': layer_frac,
             'cpu_baseline': cpu, 'cpu_baseline_torch': cpu_torch,

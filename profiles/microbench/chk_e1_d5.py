@@ -2,6 +2,7 @@
 import ctypes, os, sys
 import torch
 import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'anytime-3d-reconstruction_amd'))
+os.environ.setdefault('VOXVAE_TEST_HOOKS', '1')   # the kernel-form overrides live in lib/libvoxvae_hooks.so (voxvae/lib.py)
 from voxvae import lib as L
 lib = L.load()
 DEV = 'cuda:0'

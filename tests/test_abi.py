@@ -45,6 +45,37 @@ def test_header_symbols_exported_and_bound(built):
     assert exported == set(funcs), 'exported but undeclared: %s' % (exported - set(funcs))
 
 
+def test_release_library_reads_no_environment_and_the_hook_build_exports_the_same_abi(built, monkeypatch):
+    """'no global state'.  The kernel-form overrides of the A/B tests exist only in lib/libvoxvae_hooks.so (-DVV_TEST_HOOKS):
+    the release library holds no VV_* name and does not import getenv; the hook build exports exactly the same symbols; voxvae.lib
+    routes to it only in a process that opted in (VOXVAE_TEST_HOOKS=1) and only while a hook variable is set."""
+    from voxvae import build as vb
+    from voxvae import lib as L
+    blob = open(built, 'rb').read()
+    assert b'VV_' not in blob, 'the release library still carries a VV_* hook name'
+    und = subprocess.run(['nm', '-D', '--undefined-only', built], capture_output=True, text=True).stdout
+    assert 'getenv' not in und
+    assert os.path.exists(vb.LIB_HOOKS) and vb.is_current(hooks=True)
+    hblob = open(vb.LIB_HOOKS, 'rb').read()
+    for v in L.HOOK_VARS:
+        assert v.encode() in hblob, v
+    # every hook the sources read is routed (a new vv_hook("VV_X") without its name in HOOK_VARS would silently stay on the release library)
+    names = set()
+    for f in os.listdir(vb.CSRC):
+        names |= set(re.findall(r'vv_hook\("(VV_\w+)"\)', open(os.path.join(vb.CSRC, f)).read()))
+    assert names == set(L.HOOK_VARS), names ^ set(L.HOOK_VARS)
+    exp = lambda p: set(re.findall(r' T (vv_\w+)', subprocess.run(['nm', '-D', '--defined-only', p], capture_output=True, text=True).stdout))
+    assert exp(built) == exp(vb.LIB_HOOKS)
+    for v in L.HOOK_VARS:
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv('VOXVAE_TEST_HOOKS', '1')
+    assert L.load()._name == L.LIB_PATH
+    monkeypatch.setenv('VV_CTW_SHAPE', '32')
+    assert L.load()._name == L.HOOKS_LIB_PATH
+    monkeypatch.setenv('VOXVAE_TEST_HOOKS', '0')                   # a process that did not opt in: the variable is ignored
+    assert L.load()._name == L.LIB_PATH
+
+
 def test_no_compute_entry_points_without_gpu_but_status_calls_work(built):
     from voxvae import lib as L
     lib = L.load()

@@ -588,6 +588,47 @@ def test_streamed_evaluator_matches_one_batch_at_a_time(B, nb, ns, replicas):
         assert torch.equal(s0, s1) and torch.equal(m0, m1) and torch.equal(k0, k1) and torch.equal(p0, p1)
 
 
+def test_streamed_evaluator_repacks_on_the_callers_stream_after_a_weight_change():
+    """Round-3 advisor finding: one model serves every stream and weight packing is lazy, so after `set_weights_dict` the first
+    stream to run would pack while the next one (which waits only for the caller's stream) already reads the images.  The evaluator
+    packs on the caller's stream before it hands the step to a stream, and every stream waits for that pack: three streams submitted
+    straight after a weight change, no warm-up, against a fresh one-stream model -- ten times, bit for bit."""
+    import contextlib
+    import sys
+    import voxvae
+    from voxvae import synthetic as syn
+    from voxvae.streams import StreamedEvaluator
+    voxvae.set_default_dtype('bf16')
+    import src.module.nolbo as nolbo
+    DEV = 'cuda:0'
+    voxvae.set_default_device(DEV)
+    cfg = syn.make_config(32, 64, True)
+
+    def build(seed):
+        with contextlib.redirect_stdout(sys.stderr):
+            m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+        m._encoder.set_weights_dict(syn.make_encoder_params(cfg['encoder'], seed=seed))
+        m._decoder.set_weights_dict(syn.make_decoder_params(cfg['decoder'], seed=seed + 1))
+        return m
+
+    B = 64
+    batches = [(torch.from_numpy(syn.make_voxels(B, 32, seed=150 + i)).to(DEV), torch.from_numpy(syn.make_eps(B, 64, seed=160 + i)).to(DEV))
+               for i in range(3)]
+    ev = StreamedEvaluator(lambda: build(42), streams=3, device=DEV)
+    model = ev.models[0]
+    for rep in range(10):
+        seed = 1000 + 2 * rep
+        model._encoder.set_weights_dict(syn.make_encoder_params(cfg['encoder'], seed=seed))
+        model._decoder.set_weights_dict(syn.make_decoder_params(cfg['decoder'], seed=seed + 1))
+        got = [ev.submit(x, x, e) for x, e in batches]            # three streams, straight after the weight change
+        ev.synchronize()
+        ref_model = build(seed)
+        ref = [ref_model.eval_forward_device(x, x, e) for x, e in batches]
+        torch.cuda.synchronize()
+        for (p0, s0, m0, k0), (p1, s1, m1, k1) in zip(ref, got):
+            assert torch.equal(s0, s1) and torch.equal(m0, m1) and torch.equal(k0, k1) and torch.equal(p0, p1), rep
+
+
 def test_eval_step_as_hip_graph_is_identical():
     """voxvae.graphs.GraphedEvalStep: the 13 launches of an evaluation step are capturable (every launch goes to the capturing
     stream, every buffer comes from torch's allocator) and a replay reproduces the eager outputs bit for bit, also after the

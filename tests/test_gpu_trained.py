@@ -164,42 +164,53 @@ def test_two_pass_missing_latents_on_trained_weights(trained):
 @pytest.fixture(scope='module')
 def trained64():
     """The 64^3 VAE (the reference's native grid, test_modelnet_VAE.py:174-189; BASELINE.json configs[4]) fitted with the repo's
-    bf16 mixed-precision fit() -- the weights are just weights, the ORACLE judges the operating point -- 500 steps at batch 32."""
+    bf16 mixed-precision fit() -- the weights are just weights, the ORACLE judges the operating point -- at batch 32 on a pool of 256
+    seeded shapes, evaluated like the 32^3 model on 256 samples (192 of the pool + 64 the model has never seen): the mean of the
+    per-sample IoU difference then carries a standard error of ~4e-5 (round 3 used 48 samples: ~3e-4, a third of the bar)."""
     from voxvae import synthetic as syn
     from voxvae import trained as tr
     from oracle import c_oracle as co
-    cfg, ep, dp, info = tr.train_operating_point(voxel=64, latent=64, batch=32, pool=128, device=DEV, dtype='bf16', max_steps=1500)
+    cfg, ep, dp, info = tr.train_operating_point(voxel=64, latent=64, batch=32, pool=256, device=DEV, dtype='bf16', max_steps=3000)
     assert info['reached'], info
-    n = 48
-    x = np.concatenate([syn.make_voxels(128, 64, seed=4321)[:32], syn.make_voxels(16, 64, seed=777)], axis=0)
+    n = N_EVAL
+    x = np.concatenate([syn.make_voxels(256, 64, seed=4321)[:192], syn.make_voxels(64, 64, seed=777)], axis=0)
     eps = syn.make_eps(n, 64, seed=70)
     ref = co.vae_eval_forward(cfg, ep, dp, x, x, eps)
     iou = ref['tp'] / np.maximum(ref['tp'] + ref['fp'] + ref['fn'], 1)
-    print('\n[trained 64^3] %d fit steps; oracle IoU %.4f, logits in [%.1f, %.1f]' % (info['steps'], iou.mean(), ref['logits'].min(), ref['logits'].max()))
+    print('\n[trained 64^3] %d fit steps; oracle IoU %.4f (seen %.4f / unseen %.4f), logits in [%.1f, %.1f]'
+          % (info['steps'], iou.mean(), iou[:192].mean(), iou[192:].mean(), ref['logits'].min(), ref['logits'].max()))
     assert iou.mean() >= 0.5 and np.abs(ref['logits']).max() >= 16.0
     return dict(cfg=cfg, ep=ep, dp=dp, x=x, eps=eps, ref=ref, iou=iou, info=info)
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8/all'])
 def test_config5_geometry_iou_on_trained_weights(trained64, dtype, monkeypatch):
-    """Config 5's arithmetic at ITS geometry, at a trained operating point (48 samples: the mean carries ~3e-4 of sampling noise).
-    bf16 meets north_star's 1e-3 (measured 7e-5).  fp8 in the default 'wide' policy sits AT the bar here (measured 1.07e-3; gate 2e-3),
-    the all-layers policy well over it (2.2e-3; gate 4e-3): e4m3fn operands cost about 1e-3 of IoU per half of the network once the
-    model is fitted -- reported, bounded, not hidden."""
+    """Config 5's arithmetic at ITS geometry, at a trained operating point, 256 samples (standard error of the mean ~4e-5).
+    bf16 and the DEFAULT fp8 policy ('wide': e4m3fn operands on the two direct-kernel layers, weights rounded with error diffusion over
+    the taps an output sums -- engine.quant_fp8) meet north_star's 1e-3 with the gate AT 1e-3.  The per-layer study behind it
+    (profiles/microbench/fp8_schemes.py, profiles/r04_fp8_schemes_64.json): E2 alone 4.8e-4, D4 alone 2.7e-4, both 7.4e-4 with
+    independently rounded weights; the weight rounding's share disappears with the diffusion; per-32-channel E8M0 activation scales
+    change nothing (4.71e-4 against 4.75e-4 simulated: the error is the 3-bit mantissa of the LARGE values, not subnormals).  The
+    all-layers policy stays opt-in and over the bar; it is gated at what it measures so that the finding stays visible and bounded."""
     import voxvae
     t = trained64
     if dtype == 'fp8/all':
         monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
-    gate = {'bf16': 1e-3, 'fp8': 2e-3, 'fp8/all': 4e-3}[dtype]
+    gate = {'bf16': 1e-3, 'fp8': 1e-3, 'fp8/all': 3e-3}[dtype]
     m = _model(t, dtype.split('/')[0])
     x, eps = torch.from_numpy(t['x']).to(DEV), torch.from_numpy(t['eps']).to(DEV)
-    _, stats, _, _ = m.eval_forward_device(x, x, eps)
-    s = stats.double().cpu().numpy()
-    iou = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
-    d_mean, d_max = abs(iou.mean() - t['iou'].mean()), np.abs(iou - t['iou']).max()
-    print('\n[trained 64^3 %s] IoU ref %.4f, delta %.2e, max per-sample delta %.2e' % (dtype, t['iou'].mean(), d_mean, d_max))
+    ious = []
+    for lo in range(0, N_EVAL, 64):                       # config 5's per-GPU shard is 64 samples
+        _, stats, _, _ = m.eval_forward_device(x[lo:lo + 64].contiguous(), x[lo:lo + 64].contiguous(), eps[lo:lo + 64].contiguous())
+        s = stats.double().cpu().numpy()
+        ious.append(s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1))
+    iou = np.concatenate(ious)
+    diff = iou - t['iou']
+    d_mean, d_max, se = abs(diff.mean()), np.abs(diff).max(), diff.std(ddof=1) / np.sqrt(len(diff))
+    print('\n[trained 64^3 %s] IoU ref %.4f, delta %.2e +- %.1e (%d samples), max per-sample delta %.2e' % (dtype, t['iou'].mean(), d_mean, se, len(diff), d_max))
     assert d_mean <= gate, (dtype, d_mean)
     assert d_max <= 10 * gate, (dtype, d_max)
+    assert se <= 1.5e-4                                     # the measurement can decide: its standard error is well under the bar
 
 
 # ---------------------------------------------------------------------------------------------- the autoencoder class (config 1's model)

@@ -190,12 +190,53 @@ def test_fp8_weight_quantisation_host_side():
     wq, s = E.quant_fp8(w, 4)
     assert wq.shape == w.shape and s.shape == (16,)
     assert float(wq.abs().amax()) <= 256.0 + 1e-3 and torch.allclose(wq.abs().amax(dim=(0, 1, 2, 3)), torch.full((16,), 256.0), rtol=1e-5)
+    assert torch.equal(wq, wq.to(torch.float8_e4m3fn).float())                       # returned ON the e4m3fn grid (round 4)
     back = wq.to(torch.float8_e4m3fn).float() * s
     big = w.abs() > w.abs().amax(dim=(0, 1, 2, 3), keepdim=True) * 2.0 ** -6          # above the subnormal floor of the scaled channel
     assert float(((back - w).abs() / w.abs())[big].max()) <= 2.0 ** -4 + 1e-6
     wt = w.permute(0, 1, 2, 4, 3).contiguous()                                        # transposed-conv layout: cout at axis 3
     wq2, s2 = E.quant_fp8(wt, 3)
     assert torch.equal(s2, s) and torch.equal(wq2, wq.permute(0, 1, 2, 4, 3))
+
+
+def test_fp8_weight_error_diffusion_host_side():
+    """Round 4: the fp8 weight images are rounded with error diffusion over the taps one output sums (engine.quant_fp8 with tap groups).
+    round_e4m3 is the e4m3fn cast bit for bit; every value stays on the e4m3fn grid and within one ulp of the weight; the rounding errors
+    of a (cin, cout) pair sum to at most half an ulp over a whole tap group AND over every raster prefix of it (what a SAME-padding
+    border sums), where independent rounding leaves ~sqrt(n / 12) ulps; the transposed layout diffuses inside its 8 parity classes."""
+    if not hasattr(torch, 'float8_e4m3fn'):
+        pytest.skip('torch.float8_e4m3fn not available')
+    from voxvae import engine as E
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(100000, generator=g) * torch.exp2(torch.randint(-12, 9, (100000,), generator=g).float())
+    x = torch.cat([x, torch.tensor([0., 448., 500., -500., 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.0 ** -11, 0.9375, 0.96875, 1.0625])])
+    assert torch.equal(E.round_e4m3(x), x.clamp(-448, 448).to(torch.float8_e4m3fn).float())
+    w = torch.randn(4, 4, 4, 16, 32, generator=g) * 0.05
+    q0, s0 = E.quant_fp8(w, 4)
+    q1, s1 = E.quant_fp8(w, 4, E.CONV_TAP_GROUPS)
+    assert torch.equal(s0, s1)
+    for q in (q0, q1):
+        assert torch.equal(q, q.to(torch.float8_e4m3fn).float())                    # on the grid: the pack kernel converts exactly
+    ws = (w / s0).reshape(64, 16, 32)
+    e0, e1 = (q0.reshape(64, 16, 32) - ws), (q1.reshape(64, 16, 32) - ws)
+    top = torch.exp2(torch.floor(torch.log2(ws.abs().amax(0))) - 3)                    # the largest ulp in the group
+    # a weight's error = (carry in) - (carry out), each at most half an ulp of the value it was rounded at: bounded by the group's
+    # largest ulp (one binade of slack for a value the carry pushed up), and the error POWER is twice independent rounding's, not more
+    assert float((e1.abs() / top).max()) <= 2.0 + 1e-4
+    assert float(e1.pow(2).mean()) <= 2.6 * float(e0.pow(2).mean())
+    pre1 = e1.cumsum(0).abs().amax(0)                                                # worst raster prefix of the diffused errors
+    assert float((pre1 / top).max()) <= 0.5 + 1e-4
+    assert float(e0.sum(0).pow(2).mean().sqrt()) > 4 * float(e1.sum(0).pow(2).mean().sqrt())
+    wt = w.permute(0, 1, 2, 4, 3).contiguous()
+    q2, _ = E.quant_fp8(wt, 3, E.CONVT_TAP_GROUPS)
+    e2 = (q2 - wt / s0.view(1, 1, 1, -1, 1)).reshape(64, 32, 16)
+    assert sorted(t for grp in E.CONVT_TAP_GROUPS for t in grp) == list(range(64)) and all(len(grp) == 8 for grp in E.CONVT_TAP_GROUPS)
+    for grp in E.CONVT_TAP_GROUPS:
+        idx = torch.tensor(grp)
+        topg = torch.exp2(torch.floor(torch.log2((wt / s0.view(1, 1, 1, -1, 1)).reshape(64, 32, 16)[idx].abs().amax(0))) - 3)
+        assert float((e2[idx].sum(0).abs() / topg).max()) <= 0.5 + 1e-4
+    # parity class (pd, ph, pw) of an OUTPUT voxel reads taps 1 - p + 2a per axis: group 0 = taps with all-even indices = output parity (1,1,1)
+    assert E.CONVT_TAP_GROUPS[0] == (0, 2, 8, 10, 32, 34, 40, 42)
 
 
 def test_default_dtype_switch_accepts_the_three_modes():

@@ -20,25 +20,7 @@ import isa_lint as il
 
 SOURCES = sorted(f for f in os.listdir(il.CSRC) if f.endswith('.hip'))
 
-# kernel family -> (max asm vmcnt waits, max asm lgkmcnt waits) a look-ahead load passes before the wait that covers it: the ring
-# depth of each kernel as built today (GPU-tested).  None = not statically bounded (the wait count is selected at run time from
-# several `s_waitcnt`s; the walker cannot tell which paths are feasible).
-PINNED_WAITS = {
-    'conv_direct_kernel': (2, 2), 'conv_direct16_kernel': (2, 2), 'conv_direct_fp8_kernel': (2, 2),
-    'convT_direct_kernel': (1, 2), 'convT_direct_fp8_kernel': (1, 2),
-    'ctw_kernel': (4, 2), 'ctw16_kernel': (4, 2),
-    'final_bce_sweep_kernel': (3, 0), 'final_bce_sweepw_kernel': (3, 0), 'final_bce_sweep_fp8_kernel': (3, 0), 'final_bce_mfma_kernel': (0, 0),
-    'igemm_kernel': (None, 0), 'pg_kernel': (None, 2), 'lt_e5_kernel': (1, 0),
-    'sd_kernel': (2, 2), 'wgrad_bf16_kernel': (1, 1), 'wgrad_phase_kernel': (1, 2),
-}
-# kernels whose counted waits were written for a register-resident loop: no scratch, no spills
-NO_SCRATCH = ('conv_direct_kernel', 'conv_direct16_kernel', 'conv_direct_fp8_kernel', 'convT_direct_fp8_kernel', 'ctw_kernel', 'ctw16_kernel',
-              'final_bce_sweep_kernel', 'final_bce_sweepw_kernel', 'final_bce_sweep_fp8_kernel', 'sd_kernel', 'pg_kernel', 'wgrad_phase_kernel', 'igemm_kernel')
-
-
-def _family(mangled):
-    m = re.match(r'^_ZN12_GLOBAL__N_1\d+([A-Za-z0-9_]+?_kernel)', mangled)
-    return m.group(1) if m else mangled
+PINNED_WAITS, NO_SCRATCH, RESIDENT_BUDGET, _family = il.PINNED_WAITS, il.NO_SCRATCH, il.RESIDENT_BUDGET, il.family   # the pins live with the lint (the build enforces them)
 
 
 @pytest.mark.parametrize('src', SOURCES)
@@ -55,13 +37,6 @@ def test_no_in_flight_asm_output_is_touched_and_ring_depths_hold(src):
             assert r['max_waits_lgkm'] <= lg, '%s: an LDS read now survives %d asm lgkmcnt waits (pinned %d)' % (kernel, r['max_waits_lgkm'], lg)
         if fam in NO_SCRATCH:
             assert r['meta'].get('private_segment_fixed_size', 0) == 0 and r['meta'].get('vgpr_spill_count', 0) == 0, (kernel, r['meta'])
-
-
-# kernel family -> (source, VGPR budget): launchers that deal the work items for a fixed number of workgroups per CU.  The first layer's
-# plane form was written for four per CU (128 VGPRs); removing its timing ablations let the register allocator drift to 134 = three per
-# CU under a launcher that still dealt for four (a 1.33-round grid, ~20 % of the kernel) and nothing noticed for a round.
-RESIDENT_BUDGET = {'first_conv_chain_kernel': ('first_last.hip', 128), 'final_bce_sweep_kernel': ('first_last.hip', 168),
-                   'final_bce_sweepw_kernel': ('first_last.hip', 128)}
 
 
 def test_kernels_dealt_for_a_fixed_residency_keep_their_register_budget():
