@@ -135,7 +135,8 @@ class _ModelnetBase(object):
         if len(inputs) == 2 or category_vectors is None:
             return self._getEval_legacy(inputs, missing_prob, _eps, _mask)
         input_images, output_images, category_list = inputs
-        if missing_prob == 0.0 and isinstance(input_images, np.ndarray) and isinstance(output_images, np.ndarray):
+        from voxvae.hostio import PackedVoxels as _PV
+        if missing_prob == 0.0 and isinstance(input_images, (np.ndarray, _PV)) and isinstance(output_images, (np.ndarray, _PV)):
             out = self._getEval_host_chunked(input_images, output_images, category_list, category_vectors, _eps)
             if out is not None:
                 return out
@@ -187,10 +188,17 @@ class _ModelnetBase(object):
             return None                                  # the image -> 3D model: its inputs are images / head outputs, not voxel grids
         B = int(input_images.shape[0])
         nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2'))
-        if nchunk < 2 or B < 64 * nchunk or input_images.dtype != np.float32 or not input_images.flags['C_CONTIGUOUS']:
+
+        def usable(a):      # a float32 C-contiguous array, or a bit-packed host batch (voxvae/hostio.py: 1 bit per voxel over PCIe)
+            return isinstance(a, _H.PackedVoxels) or (a.dtype == np.float32 and a.flags['C_CONTIGUOUS'])
+
+        def upload(a, lo, hi):
+            return a.to_device(dev, lo, hi) if isinstance(a, _H.PackedVoxels) else torch.from_numpy(a[lo:hi]).to(dev)
+
+        if nchunk < 2 or B < 64 * nchunk or not usable(input_images):
             return None
         same = output_images is input_images
-        if not same and (output_images.dtype != np.float32 or not output_images.flags['C_CONTIGUOUS'] or output_images.shape != input_images.shape):
+        if not same and (not usable(output_images) or tuple(output_images.shape) != tuple(input_images.shape)):
             return None
         pd = _H.prediction_host_dtype()
         host, hview = _H.pinned_array(tuple(input_images.shape), pd)
@@ -216,8 +224,8 @@ class _ModelnetBase(object):
                 # pageable source, synchronous copy at the PCIe rate.  (Staging the chunk through a pinned block to make the upload
                 # asynchronous was measured and is NOT used: an async host -> device copy issued beside running kernels took 10-50x
                 # longer on this platform -- profiles/microbench/mb_pin.py: 78 ms against 14 ms for two matmuls with and without it.)
-                x = torch.from_numpy(input_images[lo:hi]).to(dev)
-                y = x if same else torch.from_numpy(output_images[lo:hi]).to(dev)
+                x = upload(input_images, lo, hi)
+                y = x if same else upload(output_images, lo, hi)
                 z, z_act, _, h1 = self._encode_decode_seed(x, None if eps is None else eps[lo:hi])
                 pred, _, st_ = self._dec_eng.forward(z_act, y, h1=h1)
                 hview[lo:hi].copy_(_H.device_prediction_as(pred), non_blocking=True)

@@ -59,14 +59,17 @@ def train(
         config=None, dataset_path=None,
         save_path=None, load_path=None,
         missing_pr=0.3,
-        learn='train', batch_size=72, max_iter=None, model_class='VAE', device_data=False, dump_dir=None,
+        learn='train', batch_size=72, max_iter=None, model_class='VAE', device_data=False, dump_dir=None, packed_data=False,
 ):
     import src.module.nolbo as nolbo
     cls = nolbo.nolboSingleObject_modelnet_category_VAE if model_class == 'VAE' else nolbo.nolboSingleObject_modelnet_category_AE
     model = cls(nolbo_structure=config, learning_rate=learning_rate)
     voxel = config['encoder']['input_shape'][0]
     # device_data: the split stays in HBM as packed bits and batches are gathered + unpacked on the GPU (no per-iteration copy)
-    loader = (deviceDataLoader if device_data else dataLoader)(data_path=dataset_path, trainortest='test', voxel=voxel)
+    if packed_data and not device_data:     # host loader, bits instead of floats (voxvae/hostio.py: PackedVoxels)
+        loader = dataLoader(data_path=dataset_path, trainortest='test', voxel=voxel, packed=True)
+    else:
+        loader = (deviceDataLoader if device_data else dataLoader)(data_path=dataset_path, trainortest='test', voxel=voxel)
     category_vectors = None
     if load_path is not None:
         print('load weights...')
@@ -90,5 +93,5 @@ if __name__ == '__main__':
     sys.exit(0 if train(
         learning_rate=a.lr, config=C.make_config(a.latent, a.voxel, True), dataset_path=a.dataset_path,
         load_path=a.load_path, missing_pr=a.missing_pr, batch_size=a.batch, max_iter=a.max_iter, device_data=a.device_data,
-        dump_dir=a.dump_dir,
+        dump_dir=a.dump_dir, packed_data=a.packed_data,
     ) is not None else 1)

@@ -23,11 +23,14 @@ def set_fp8_policy(policy):
     """Which MFMA layers run on e4m3fn operands in 'fp8' mode (engines built afterwards).
 
     'wide' (default): the layers that have a direct fp8 kernel -- the widest encoder and decoder layer (E2 / D4 at 32^3:
-           62 % of the path's FLOPs and nearly all of the time fp8 saves).  Measured at the TRAINED operating point
-           (tests/test_gpu_trained.py; 256 samples): mean IoU within 1e-3 of the float32 oracle, north_star's bar.
+           62 % of the path's FLOPs and nearly all of the time fp8 saves).  Measured at the TRAINED operating points
+           (tests/test_gpu_trained.py; 256 samples each): mean IoU within 5.0e-4 (32^3) / 4.3e-4 (64^3, BASELINE config 5's geometry)
+           of the float32 oracle -- north_star's bar is 1e-3.  The weight images are rounded with error diffusion over the taps an
+           output sums (engine.quant_fp8), which removes the weight rounding's share of that cost.
     'all':  every layer whose Cin is a multiple of 128 (and E2 through tap-pair rows), as in rounds 1-2.  Fastest, but each
            fp8 layer adds ~1-3 % of noise to its pre-activations (3 mantissa bits on both operands), and at a trained operating
-           point the sum costs 1.7e-3 of mean IoU -- beyond the bar; the layers between E3 and D3 also gain little time."""
+           point the sum costs 1.44e-3 (32^3) / 1.23e-3 (64^3) of mean IoU -- beyond the bar; the layers between E3 and D3 also
+           gain little time."""
     if policy not in ('wide', 'all'):
         raise ValueError(policy)
     _DEFAULTS['fp8_policy'] = policy

@@ -42,6 +42,9 @@ class DeviceArray(object):
         return self.t.shape[0]
 
     def __getitem__(self, idx):
+        """A DeviceArray of the indexed part (still on the device); `np.array(a[idx])` / `float(a[idx])` bring it to the host.
+        (HostPrediction, the host-array path's `pred`, indexes into its downloaded block and returns numpy: both support
+        `np.array(pred[i])`, which is what the reference's callers do.)"""
         return DeviceArray(self.t[idx])
 
     def __repr__(self):
@@ -51,6 +54,11 @@ class DeviceArray(object):
 def as_device_f32(x, device):
     """numpy / DeviceArray / torch -> contiguous float32 tensor on `device` (host->device copy if needed)."""
     if isinstance(x, DeviceArray):
+        x = x.t
+    from .hostio import HostPrediction, PackedVoxels
+    if isinstance(x, PackedVoxels):                    # 1 bit per voxel over PCIe, unpacked on the device (voxvae/hostio.py)
+        return x.to_device(device)
+    if isinstance(x, HostPrediction):
         x = x.t
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float32).contiguous()

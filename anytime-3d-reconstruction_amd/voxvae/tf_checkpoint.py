@@ -63,6 +63,56 @@ def _mask(crc):
     return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xFFFFFFFF
 
 
+_CRC_LANE = 4096          # bytes per lane of crc32c_bulk
+_CRC_ADV = None           # [4][256] uint32: the operator "append _CRC_LANE zero bytes" on a raw CRC register, byte-sliced
+
+
+def _crc_advance_tables():
+    """CRC registers are linear over GF(2): feeding n zero bytes maps the register through a fixed 32 x 32 bit matrix.  The images of
+    the 32 unit vectors are computed once by running the byte-wise recurrence, then folded into four 256-entry tables."""
+    global _CRC_ADV
+    if _CRC_ADV is None:
+        t = np.array(_crc_table(), dtype=np.uint32)
+        basis = np.uint32(1) << np.arange(32, dtype=np.uint32)
+        for _ in range(_CRC_LANE):
+            basis = t[basis & 0xFF] ^ (basis >> 8)
+        adv = np.zeros((4, 256), dtype=np.uint32)
+        for byte in range(4):
+            for v in range(256):
+                acc = np.uint32(0)
+                for bit in range(8):
+                    if v >> bit & 1:
+                        acc ^= basis[8 * byte + bit]
+                adv[byte, v] = acc
+        _CRC_ADV = adv
+    return _CRC_ADV
+
+
+def crc32c_bulk(data):
+    """crc32c of a large buffer (tensor bytes: tens of MB) in numpy: the buffer is cut into lanes of 4096 bytes whose raw registers
+    are advanced TOGETHER, one byte position per numpy operation, and the lane results are chained with the precomputed
+    "append 4096 zero bytes" operator (CRC linearity).  Equal to crc32c() on every input (tests/test_host_logic.py)."""
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    n = a.size
+    if n < 4 * _CRC_LANE:
+        return crc32c(a.tobytes())
+    lanes = n // _CRC_LANE
+    body = a[:lanes * _CRC_LANE].reshape(lanes, _CRC_LANE)
+    t = np.array(_crc_table(), dtype=np.uint32)
+    reg = np.zeros(lanes, dtype=np.uint32)
+    reg[0] = 0xFFFFFFFF                                  # the initial register enters through the first lane only
+    for j in range(_CRC_LANE):
+        reg = t[(reg ^ body[:, j]) & 0xFF] ^ (reg >> 8)
+    adv = _crc_advance_tables()
+    c = 0
+    for r in reg.tolist():                               # c = advance(c) ^ lane register
+        c = int(adv[0, c & 0xFF] ^ adv[1, (c >> 8) & 0xFF] ^ adv[2, (c >> 16) & 0xFF] ^ adv[3, (c >> 24) & 0xFF]) ^ r
+    tt = _crc_table()
+    for b in a[lanes * _CRC_LANE:].tolist():             # the tail, byte-wise
+        c = tt[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
 # ---------------------------------------------------------------------------------------------- varints / protobuf pieces
 def _get_varint(buf, pos):
     out, shift = 0, 0
@@ -199,6 +249,9 @@ def read_checkpoint(prefix):
         if shard not in shards:
             shards[shard] = np.memmap('%s.data-%05d-of-%05d' % (prefix, shard, num_shards), dtype=np.uint8, mode='r')
         raw = np.asarray(shards[shard][offset:offset + size])
+        stored = e.get(6, [0])[0]
+        if stored and _mask(crc32c_bulk(raw)) != stored:      # BundleEntryProto.crc32c = masked crc32c of the tensor's bytes (0: not recorded)
+            raise ValueError('checkpoint tensor %r: crc32c mismatch (data shard corrupt or misread)' % key)
         shape = _shape_of(e.get(2, [b''])[0])
         if dt == _DT_BFLOAT16:
             arr = (raw.view('<u2').astype(np.uint32) << 16).view(np.float32)
@@ -246,7 +299,8 @@ def write_checkpoint(prefix, tensors, block_bytes=4096):
                 raise NotImplementedError('write_checkpoint: dtype %s' % a.dtype)
             raw = a.tobytes()
             f.write(raw)
-            entries.append((k.encode(), _entry_proto(_DT_OF[a.dtype], a.shape, 0, offset, len(raw), 0)))
+            # masked crc32c of the tensor bytes: TensorFlow's BundleReader::GetValue compares it and returns DataLoss on a mismatch
+            entries.append((k.encode(), _entry_proto(_DT_OF[a.dtype], a.shape, 0, offset, len(raw), _mask(crc32c_bulk(raw)))))
             offset += len(raw)
     with open(prefix + '.index', 'wb') as f:
         pos, index, cur, cur_bytes = 0, [], [], 0
@@ -309,7 +363,8 @@ def load_keras_checkpoint(prefix, own_shapes):
 
 def save_keras_checkpoint(prefix, params_in_creation_order):
     """The inverse: {own name: array} (creation order) -> a TF checkpoint with Keras' object-graph keys, loadable by
-    `keras_model.load_weights(prefix)` on a TensorFlow box as far as the tensor entries go (no object-graph proto is written;
+    `keras_model.load_weights(prefix)` on a TensorFlow box as far as the tensor entries go (every entry carries the masked crc32c of
+    its bytes, which BundleReader checks; UNTESTED against TensorFlow itself, which is not installable here; no object-graph proto is written;
     Keras falls back to name-based matching of the `layer_with_weights-*` keys only when the graph is present, so prefer the
     `.npz` route of INTEGRATION.md section C for that direction)."""
     keys = dict((name, key) for key, name in keras_object_graph_keys(list(params_in_creation_order)))

@@ -30,9 +30,21 @@ def _st():
 class GradBuckets:
     """Flat gradient storage: every trainable tensor's gradient is a view into one of a few large float32
     buffers, so the cross-rank sum is a handful of large all-reduces (per-link-bound xGMI rings want few, big
-    messages) issued in backward order.  Pure tensor bookkeeping: usable (and tested) on CPU with gloo."""
+    messages) issued in backward order.  Pure tensor bookkeeping: usable (and tested) on CPU with gloo.
 
-    def __init__(self, named_shapes, device, bucket_bytes=32 << 20):
+    wire='f32' (default): one SUM all-reduce per bucket on the float32 buffer (106 MB per step at the 32^3 model).
+    wire='bf16' (round 4): half the bytes, and float32 ACCUMULATION -- a bucket is cut into one shard per rank and reduced as
+        all-to-all (every rank sends shard j of its bf16 copy to rank j) -> float32 sum of the `world` received shards in rank order
+        (the same order on every rank: deterministic) -> all-gather of the reduced shards as bf16 -> widened into the float32 bucket.
+        The values on the wire are bf16, the sum is not: one rounding of each contribution and one of the result, whatever the
+        number of ranks (a bf16 ring all-reduce rounds after every hop).  It is also the direct reduce-scatter + all-gather that
+        the fully connected xGMI topology wants: every rank talks to its 7 peers at once instead of pushing 2 x 7/8 of the bucket
+        through one ring link (DESIGN.md section 5 has the bytes per link)."""
+
+    def __init__(self, named_shapes, device, bucket_bytes=32 << 20, wire='f32', world_size=1):
+        if wire not in ('f32', 'bf16'):
+            raise ValueError(wire)
+        self.wire, self.world = wire, max(int(world_size), 1)
         self.views, self.buckets = {}, []
         cur, cur_n = [], 0
         plan = []
@@ -49,13 +61,17 @@ class GradBuckets:
         if cur:
             plan.append((cur, cur_n))
         self.bucket_of, self.members = {}, []
+        gran = 8 * self.world                    # a bucket splits into `world` shards of whole 16-byte bf16 pieces
         for items, total in plan:
+            total = (total + gran - 1) // gran * gran
             buf = torch.zeros(total, dtype=torch.float32, device=device)
             self.buckets.append(buf)
             self.members.append([name for name, _, _, _ in items])
             for name, shape, n, off in items:
                 self.views[name] = buf[off:off + n].view(*shape)
                 self.bucket_of[name] = len(self.buckets) - 1
+        self._wire_bufs = None       # wire='bf16': per bucket (bf16 send copy, received shards [world, shard], reduced shard, gathered)
+        self._comm_stream = None
         self.always_reduce = False   # True: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)
         self.profile = None          # a list: finish() appends (event before, event after) -- the EXPOSED collective time
         self.begin_step()
@@ -74,8 +90,13 @@ class GradBuckets:
         torch.cuda.synchronize()
         e0.record()
         for _ in range(repeats):
-            for b in self.buckets:
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+            for i, b in enumerate(self.buckets):
+                if self.wire == 'bf16':
+                    w = self._launch_bf16(i, group, dist)
+                    if w:
+                        w()
+                else:
+                    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / repeats
@@ -105,9 +126,54 @@ class GradBuckets:
         self.launch_order.append(b)
         if self._distributed(group):
             import torch.distributed as dist
-            self._works[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            if self.wire == 'bf16':
+                self._works[b] = self._launch_bf16(b, group, dist)
+            else:
+                self._works[b] = dist.all_reduce(self.buckets[b], op=dist.ReduceOp.SUM, group=group, async_op=True)
         else:
             self._works[b] = False
+
+    def wire_bytes_per_step(self):
+        """Bytes one rank puts on the wire per step (both phases of a reduction counted), for the bench line."""
+        n = sum(int(b.numel()) for b in self.buckets)
+        w = self.world
+        per_elem = 4 if self.wire == 'f32' else 2
+        return int(2 * (w - 1) / max(w, 1) * n * per_elem)
+
+    def _launch_bf16(self, b, group, dist):
+        """Direct reduce-scatter + all-gather with bf16 on the wire and a float32 sum (class docstring).  On a GPU the three steps
+        run on a side stream behind an event on the launch stream, so that the backward kernels enqueued after this call do not wait
+        for them; finish() joins the side stream.  Returns a callable that finish() invokes (the Work-like object of this form)."""
+        buf = self.buckets[b]
+        world = dist.get_world_size(group)
+        if buf.numel() % (8 * world):
+            raise ValueError('bucket of %d elements does not split into %d shards (GradBuckets(world_size=...) must be the group size)' % (buf.numel(), world))
+        shard = buf.numel() // world
+        if self._wire_bufs is None:
+            self._wire_bufs = {}
+        if b not in self._wire_bufs:
+            bf = torch.bfloat16
+            self._wire_bufs[b] = (torch.empty(buf.numel(), dtype=bf, device=buf.device), torch.empty(world, shard, dtype=bf, device=buf.device),
+                                  torch.empty(shard, dtype=bf, device=buf.device), torch.empty(buf.numel(), dtype=bf, device=buf.device))
+        send, recv, red, full = self._wire_bufs[b]
+
+        def chain():
+            send.copy_(buf)                                              # one rounding of this rank's contribution
+            dist.all_to_all_single(recv.view(-1), send, group=group)     # recv[r] = rank r's copy of MY shard
+            red.copy_(recv.float().sum(dim=0))                           # float32 sum in rank order, one rounding of the result
+            dist.all_gather_into_tensor(full, red, group=group)
+            buf.copy_(full)
+
+        if not buf.is_cuda:
+            chain()
+            return False
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=buf.device)
+        cur = torch.cuda.current_stream(buf.device)
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            chain()
+        return lambda: torch.cuda.current_stream(buf.device).wait_stream(self._comm_stream)
 
     def finish(self, group=None):
         prof = self.profile is not None and self.buckets[0].is_cuda
@@ -119,7 +185,7 @@ class GradBuckets:
                 self._launch(b, group)
         for w in self._works:
             if w:
-                w.wait()
+                w() if callable(w) else w.wait()
         if prof:
             e1.record()
             self.profile.append((e0, e1))
@@ -135,7 +201,8 @@ class _BN:
 
 
 class Trainer:
-    def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None):
+    def __init__(self, enc, dec, variational=True, learning_rate=1e-4, world_size=1, group=None, grad_wire=None):
+        """grad_wire: 'f32' (default) or 'bf16' -- what the gradient buckets put on the wire (GradBuckets); VOXVAE_GRAD_WIRE sets the default."""
         if enc is not None and enc.dt != dec.dt:
             raise ValueError('encoder and decoder engines must share one activation dtype')
         if dec.fp8 or (enc is not None and enc.fp8):
@@ -159,7 +226,7 @@ class Trainer:
         names += [('dec/' + k, v.shape) for k, v in dec.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         # backward order: decoder tail first ... encoder head last
         self.order = list(reversed(names))
-        self.grads = GradBuckets(self.order, self.dev)
+        self.grads = GradBuckets(self.order, self.dev, wire=grad_wire or os.environ.get('VOXVAE_GRAD_WIRE', 'f32'), world_size=self.world)
         self.m = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
         self.v = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
 

@@ -68,6 +68,9 @@ def parse(argv=None):
                     help="'eval' = the BASELINE.json headline (default); 'train' = fit() steps (gradients all-reduced over RCCL for N>1)")
     ap.add_argument('--streams', type=int, default=3,
                     help='HIP streams per GPU: independent batches are issued round-robin on them, one model (the engines keep a workspace per stream); 1 = one batch at a time')
+    ap.add_argument('--grad-wire', default='f32', choices=['f32', 'bf16'],
+                    help="--mode train: what the gradient buckets put on the wire: 'f32' = one all-reduce per bucket; 'bf16' = direct reduce-scatter + "
+                         "all-gather with bf16 on the wire and a float32 sum (voxvae/train.py:GradBuckets), half the bytes")
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="process-group backend ('nccl' = RCCL; 'gloo' with --dry-run only)")
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / collective rehearsal without a GPU: ranks fabricate per-rank metrics and run the same reduction code')
@@ -265,7 +268,7 @@ def time_steps(fn, steps, warmup):
 def bench_train(a, model, x, eps, world, rank, dev, dist):
     """Training-step throughput (BASELINE.json configs[3]: batch sharded over the ranks, gradients summed by RCCL)."""
     from voxvae import train as T
-    tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-4, world_size=world)
+    tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-4, world_size=world, grad_wire=a.grad_wire)
     # Under a launcher the gradient buckets always go through RCCL, also with one rank (same code path as N > 1)
     tr.grads.always_reduce = dist is not None
     for _ in range(a.warmup):
@@ -294,6 +297,7 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
         tr.grads.profile = None
         total = tr.grads.blocking_all_reduce_ms()
         overlap = {'buckets': len(tr.grads.buckets), 'bucket_bytes': [int(b.numel() * 4) for b in tr.grads.buckets],
+                   'wire': tr.grads.wire, 'wire_bytes_per_rank_per_step': tr.grads.wire_bytes_per_step(),
                    'all_reduce_ms_back_to_back': total, 'exposed_ms_after_backward': exposed,
                    'overlapped_fraction': (max(0.0, 1.0 - exposed / total) if total > 0 else None),
                    'launch_order': list(tr.grads.launch_order)}
@@ -323,11 +327,30 @@ def dry_run(a, world, rank):
                     400.0 * a.batch, float(a.batch)])
     el = 1e-3 * a.steps * (1 + rank)
     sums, el, nranks = reduce_metrics(dist, vec, el, 'cpu')
+    # what else differs per rank in the real run: the shard seeds (voxels 1234 + rank, epsilon 7 + rank in main()) and, in training,
+    # the gradient buckets -- a small GradBuckets with the requested wire format goes through the same collectives at this world size
+    seeds, grads = [[1234 + rank, 7 + rank]], None
+    if dist is not None:
+        allseeds = [None] * world
+        dist.all_gather_object(allseeds, seeds[0])
+        seeds = allseeds
+        from voxvae.train import GradBuckets
+        gb = GradBuckets([('dec/convT4/kernel', (4, 4, 4, 1, 64)), ('enc/bn0/beta', (63,)), ('enc/conv0/kernel', (4, 4, 4, 1, 64))], 'cpu',
+                         bucket_bytes=1 << 14, wire=a.grad_wire, world_size=world)
+        for i, n in enumerate(gb.views):
+            gb.views[n].fill_(float(rank + 1) * (i + 1))
+        gb.begin_step()
+        for n in list(gb.views):
+            gb.ready([n])
+        gb.finish()
+        want = float(world * (world + 1) // 2)
+        grads = {'wire': a.grad_wire, 'buckets': len(gb.buckets), 'wire_bytes_per_rank_per_step': gb.wire_bytes_per_step(),
+                 'summed_correctly': bool(all(torch.all(gb.views[n] == want * (i + 1)) for i, n in enumerate(gb.views)))}
     if rank == 0:
         print(json.dumps({'metric': '32^3 voxel reconstructions/sec at batch=256; IoU delta vs reference', 'value': 0.0, 'unit': 'reconstructions/s',
                           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el / max(a.steps, 1), 'higher_is_better': True,
                           'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'none', 'dry_run': True, 'rccl_world_size': nranks,
-                          'backend': a.backend, 'global_metrics': global_metrics(sums),
+                          'backend': a.backend, 'global_metrics': global_metrics(sums), 'shard_seeds': seeds, 'gradient_buckets': grads,
                           'config': {'workload': 'DRY RUN: launcher and metric reduction only, no kernel ran', 'global_batch': a.batch * world}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -505,7 +528,23 @@ def main():
         hostio.set_prediction_host_dtype('uint8')
         dth8 = time_steps(host_call, 20, 5)
         hostio.set_prediction_host_dtype('float32')
+        # the same call with the batch kept as bits on the host (hostio.PackedVoxels: what dataLoader(packed=True) serves): 1 bit per voxel up
+        xp = hostio.pack_voxels(xh)
+
+        def host_call_packed():
+            out = model.getEval(inputs=(xp, xp, oh), category_vectors=cats, missing_prob=0.0, _eps=epsh)
+            return np.array(out[0]), float(out[1])
+
+        dtp = time_steps(host_call_packed, 20, 5)
+        hostio.set_prediction_host_dtype('uint8')
+        dtp8 = time_steps(host_call_packed, 20, 5)
+        hostio.set_prediction_host_dtype('float32')
         h2d = {'value': a.batch / dth, 'unit': 'reconstructions/s', 'ms_per_call': 1e3 * dth,
+               'bit_packed_input': {'value': a.batch / dtp, 'ms_per_call': 1e3 * dtp, 'uint8_occupancy_return': {'value': a.batch / dtp8, 'ms_per_call': 1e3 * dtp8},
+                                    'what': 'getEval(PackedVoxels x, x, one-hot) -> np.array(pred): the batch is kept as 1 bit per voxel on the host (made once where the '
+                                            'data enters: dataLoader(packed=True) / hostio.pack_voxels), %.2f MB host->device + vv_unpack_bits_gather; float32 '
+                                            'probabilities back (%.1f MB) or the opt-in uint8 occupancy (%.1f MB); bit-identical to the float32-array call'
+                                            % (xp.bits.nbytes / 1e6, xh.nbytes / 1e6, xh.nbytes / 4e6)},
                'what': 'getEval(numpy x, x, one-hot) -> np.array(pred): %.1f MB host->device (input and target are the same array, as in '
                        'test_modelnet_VAE.py:115: uploaded once; pageable source) + %.1f MB device->host per call into a recycled pinned '
                        'block; two-chunk pipeline on two streams (voxvae/hostio.py); bit-identical to the device-resident path'

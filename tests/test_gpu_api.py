@@ -720,7 +720,7 @@ def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
     assert free_before >= 1 and held == 1
     o3 = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
     assert sum(len(v) for v in hostio._POOL.values()) == free_before - 1 and hostio._OUT['n'] == held + 1
-    view = np.array(o3[0])[3]                                    # a view keeps the block out of the pool ...
+    view = np.array(o3[0])[3]                                    # a view of the handed-out block keeps it out of the pool ...
     del o3
     gc.collect()
     assert hostio._OUT['n'] == held + 1
@@ -742,6 +742,91 @@ def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
         np.testing.assert_array_equal(p16, ref_pred.astype(np.float16))
     finally:
         hostio.set_prediction_host_dtype('float32')
+
+
+def test_bit_packed_host_batches_give_the_float_batches_results():
+    """Round 4: `voxvae.hostio.PackedVoxels` -- a host batch kept as 1 bit per voxel that reads like the float32 array -- through every
+    model method that takes a batch: the same bits as the float32 host array and as the device tensor (getEval's pipeline, the
+    missing-latent path, getLatent, fit), `dataLoader(packed=True)` serving such batches, the read-only later views of a
+    HostPrediction, and the cap on pooled pinned memory."""
+    import gc
+    import voxvae
+    from voxvae import hostio
+    from voxvae import synthetic as syn
+    from src.dataset_loader.modelnet_dataset import dataLoader
+    voxvae.set_default_dtype('bf16')
+    voxvae.set_default_device('cuda:0')
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(32, 64, True)
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(syn.make_encoder_params(cfg['encoder']))
+    m._decoder.set_weights_dict(syn.make_decoder_params(cfg['decoder']))
+    B = 160
+    x, eps = syn.make_voxels(B, 32, seed=31), syn.make_eps(B, 64, seed=32)
+    oh, cats = syn.make_onehot(B, 40), syn.make_category_vectors(40, 64)
+    xp = hostio.pack_voxels(x)
+    assert xp.shape == x.shape and xp.dtype == np.float32 and xp.bits.nbytes * 32 == x.nbytes
+    np.testing.assert_array_equal(np.array(xp), x)
+    np.testing.assert_array_equal(np.array(xp[7:19]), x[7:19])
+    assert torch.equal(xp.to_device('cuda:0'), torch.from_numpy(x).to('cuda:0'))
+    ref = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    ref_pred, ref_z = np.array(ref[0]), np.array(m._z_category)
+    out = m.getEval(inputs=(xp, xp, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    assert isinstance(out[0], hostio.HostPrediction)
+    np.testing.assert_array_equal(np.array(out[0]), ref_pred)
+    np.testing.assert_array_equal(np.array(m._z_category), ref_z)
+    assert [float(v) for v in out[1:5]] == [float(v) for v in ref[1:5]]
+    # a float target with a packed input, the missing-latent path (two decoder passes), getLatent
+    y = syn.make_voxels(B, 32, seed=33)
+    o2 = m.getEval(inputs=(xp, y, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    r2 = m.getEval(inputs=(x, y, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    np.testing.assert_array_equal(np.array(o2[0]), np.array(r2[0]))
+    mask, eps2 = syn.make_mask(B, 64, 0.5, seed=34), syn.make_eps(B, 64, seed=35)
+    o3 = m.getEval(inputs=(xp, xp, oh), category_vectors=cats, missing_prob=0.5, _eps=eps, _mask=mask, _eps2=eps2)
+    r3 = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.5, _eps=eps, _mask=mask, _eps2=eps2)
+    for a, b in zip(o3, r3):
+        np.testing.assert_array_equal(np.array(a), np.array(b))
+    np.testing.assert_array_equal(m.getLatent(xp, _eps=eps), m.getLatent(x, _eps=eps))
+    # the loader: same sample stream as the float loader under the same np.random seed, batches that read like the float arrays
+    np.random.seed(5)
+    lf = dataLoader('synthetic:192:32', 'test')
+    np.random.seed(5)
+    lp = dataLoader('synthetic:192:32', 'test', packed=True)
+    bf, bp = lf.getNextBatch(160), lp.getNextBatch(160)
+    assert isinstance(bp['input_images'], hostio.PackedVoxels) and bp['input_images'].shape == bf['input_images'].shape
+    np.testing.assert_array_equal(np.array(bp['input_images']), bf['input_images'])
+    np.testing.assert_array_equal(bp['class_list'], bf['class_list'])
+    ol = m.getEval(inputs=(bp['input_images'], bp['input_images'], bp['class_list']), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    of = m.getEval(inputs=(bf['input_images'], bf['input_images'], bf['class_list']), category_vectors=cats, missing_prob=0.0, _eps=eps)
+    np.testing.assert_array_equal(np.array(ol[0]), np.array(of[0]))
+    # fit() takes it too (float32 training step on a small model would be slow to build here: the bf16 model's own step)
+    kl_a = [float(v) for v in m.fit((xp[:32], xp[:32]), _eps=eps[:32])]
+    assert all(np.isfinite(kl_a))
+    # HostPrediction: the first np.array() is the block itself (writable), later views are read-only, a second np.array() is a copy
+    hp = m.getEval(inputs=(xp, xp, oh), category_vectors=cats, missing_prob=0.0, _eps=eps)[0]
+    first = np.array(hp)
+    assert first.flags.writeable and np.shares_memory(first, hp.host)
+    later = hp.numpy()
+    assert not later.flags.writeable and not hp[3].flags.writeable and np.shares_memory(later, first)
+    second = np.array(hp)
+    assert second.flags.writeable and not np.shares_memory(second, first)
+    with pytest.raises(ValueError):
+        later[0, 0, 0, 0, 0] = 1.0
+    # pooled pinned memory is bounded: free blocks beyond the cap are released, least recently used size first
+    del hp, first, later, second, out, o2, r2, o3, r3, ol, of, ref
+    gc.collect()
+    keep = hostio._STATE['max_pooled_bytes']
+    try:
+        hostio._STATE['max_pooled_bytes'] = 48 << 20
+        for n in (3, 5, 7, 9, 11, 13):
+            t = torch.zeros(n << 20, dtype=torch.float32, device='cuda:0')
+            a = hostio.to_host(t)
+            assert a.shape == (n << 20,) and not a.any()
+            del a
+            gc.collect()
+            assert hostio.pooled_bytes() <= 48 << 20
+    finally:
+        hostio._STATE['max_pooled_bytes'] = keep
 
 
 @pytest.mark.parametrize('dtype,D', [('f32', 32), ('bf16', 32), ('f32', 16)])

@@ -96,15 +96,16 @@ def test_f32_logits_occupancy_and_saturated_bce_on_trained_weights(trained):
 def test_reduced_precision_iou_on_trained_weights(trained, dtype, monkeypatch):
     """bf16 and the default fp8 policy ('wide': the direct-kernel layers E2 / D4) meet north_star's bar at the trained operating
     point: mean IoU within 1e-3 of the oracle.  Per-sample: bf16 within 5e-3; fp8 within 1e-2 (3 mantissa bits on both operands of
-    62 % of the FLOPs).  'fp8/all' (every eligible layer, rounds 1-2's mode) does NOT meet the 1e-3 bar here -- measured 1.7e-3,
-    always a LOSS of IoU: each fp8 layer adds 1-3 % of noise to its pre-activations and a fitted model sits at an optimum -- it is
-    gated at 3e-3 so that the finding stays visible and bounded."""
+    62 % of the FLOPs; measured 5.0e-4 with the error-diffused weight images of round 4, 7.1e-4 before).  'fp8/all' (every eligible
+    layer, rounds 1-2's mode) does NOT meet the 1e-3 bar here -- measured 1.44e-3 (1.7e-3 before round 4), always a LOSS of IoU: each
+    fp8 layer adds 1-3 % of noise to its pre-activations and a fitted model sits at an optimum -- it is gated at 2e-3 so that the
+    finding stays visible and bounded."""
     import voxvae
     t = trained
     ref = t['ref']
     if dtype == 'fp8/all':
         monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
-    mean_gate, sample_gate = {'bf16': (1e-3, 5e-3), 'fp8': (1e-3, 1e-2), 'fp8/all': (3e-3, 2e-2)}[dtype]
+    mean_gate, sample_gate = {'bf16': (1e-3, 5e-3), 'fp8': (1e-3, 1e-2), 'fp8/all': (2e-3, 2e-2)}[dtype]
     probs, logits, stats, stats2, kl = _run(_model(t, dtype.split('/')[0]), t)
     for s in (stats, stats2):
         iou = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
@@ -196,7 +197,7 @@ def test_config5_geometry_iou_on_trained_weights(trained64, dtype, monkeypatch):
     t = trained64
     if dtype == 'fp8/all':
         monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
-    gate = {'bf16': 1e-3, 'fp8': 1e-3, 'fp8/all': 3e-3}[dtype]
+    gate = {'bf16': 1e-3, 'fp8': 1e-3, 'fp8/all': 2e-3}[dtype]          # measured (round 4): 2.5e-5 / 4.3e-4 / 1.23e-3
     m = _model(t, dtype.split('/')[0])
     x, eps = torch.from_numpy(t['x']).to(DEV), torch.from_numpy(t['eps']).to(DEV)
     ious = []
