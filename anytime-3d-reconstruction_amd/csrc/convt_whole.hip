@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -452,6 +453,331 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
     cw_wait_vm<0>();
 }
 
+
+// ---- round 4: FOUR waves, one per SIMD, 128 cells x 64 channels each, two accumulator sets (`ctw4_kernel`).
+// In-kernel stamps on ctw16_kernel put a workgroup at 207 k cycles against 131 k of MFMA work: ~35 k are the eight
+// parity epilogues (VALU with the matrix pipe idle: at two waves per SIMD an epilogue slice only displaced the partner wave's MFMAs), the
+// rest barrier skew and the LDS read bursts of two waves that leave every barrier in phase.  Here a SIMD holds ONE wave, so what sits
+// between two of its MFMAs is its own to fill: the wave owns input planes 2w, 2w + 1 (8 cell tiles x 4 channel tiles = 32 accumulators of
+// 16 x 16), reads 12 fragments per 32 MFMAs instead of 16, and keeps TWO accumulator sets (256 registers of the unified 512) so that the
+// BatchNorm + activation + pack + store of parity p runs in the gaps between the MFMAs of parity p + 1 -- one output unit (two channel
+// tiles of one cell tile: 8 values, one 16-byte store) per chunk, cut into pieces of one to three VALU instructions, one piece per gap.
+// LDS images, slot keys, ring, barrier placement and the per-accumulator summation order are ctw16_kernel's: the outputs are the same bits.
+// C4_ABL (diagnostic builds only, profiles/microbench/c4_ablate.py; 0 in the tree's build): 1 no epilogue pieces in the loop, 2 no
+// barrier, 4 no weight LDS-DMA in the loop, 8 no fragment reads in the loop, 16 no MFMAs, 32 no activation math (stages 1..5), 64 no
+// accumulator reads / packs / swaps / stores in the loop, 128 no v_exp -- wrong results, timing only
+#ifndef C4_ABL
+#define C4_ABL 0
+#endif
+template <int N, class Fn, int... I>
+__device__ __forceinline__ void c4_static_for_impl(Fn &&fn, std::integer_sequence<int, I...>) {
+    (fn(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void c4_static_for(Fn &&fn) {
+    c4_static_for_impl<N>(fn, std::make_integer_sequence<int, N>{});
+}
+#define C4_SB __builtin_amdgcn_sched_barrier(0)
+#define C4_RD(D, A, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(D) : "v"(A), "n"(OFF) : "memory")
+#define C4_WAIT(F)                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                             \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]), "+v"(F[8]),       \
+                   "+v"(F[9]), "+v"(F[10]), "+v"(F[11])                                                                             \
+                 :                                                                                                                  \
+                 : "memory")
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void ctw4_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      __bf16 *__restrict__ y, int npar) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..3: input planes 2 wave, 2 wave + 1
+    const int ps = 8 / npar;
+    const int b = (int)blockIdx.x / ps, p0 = ((int)blockIdx.x % ps) * npar;
+    const int NC = npar * 16;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    const u32x4 rsx = vv_make_rsrc(x + (size_t)b * (512 * 128), CW_X);
+    const u32x4 rsw = vv_make_rsrc(w, 64 * 128 * 64 * 2);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)b * (4096 * 64), 0, 4096 * 64 * 2, 0x00020000);
+    {   // the sample: 128 pieces of 4 voxels, 32 per wave
+        const int pos = lane & 15, vsub = lane >> 4;
+#pragma unroll 1
+        for (int i = 0; i < 32; ++i) {
+            const int it = i * 4 + wave;
+            const int v = it * 4 + vsub;
+            vv_dma16(rsx, (unsigned)(v * 256 + ((pos ^ ((2 * v) & 15)) << 4)), lds0 + it * 1024);
+        }
+    }
+    // weight chunk [64 co][64 ci] = 8 pieces of 8 rows: this wave's pieces 2 wave, 2 wave + 1
+    const int wr0 = wave * 16 + (lane >> 3), wr1 = wr0 + 8;
+    const unsigned wv0 = (unsigned)(wr0 * 128 + (((lane & 7) ^ ((wr0 >> 1) & 7)) << 4));
+    const unsigned wv1 = (unsigned)(wr1 * 128 + (((lane & 7) ^ ((wr1 >> 1) & 7)) << 4));
+    auto issue_w = [&](int c, int s) {
+        const int cc = c < NC ? c : NC - 1;                             // (the tail re-fetches the last chunk into a free stage)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((p0 * 16 + cc) * CW_WST);
+        vv_dma16(rsw, wv0, soff, lds0 + CW_RING + s * CW_WST + wave * 2048);
+        vv_dma16(rsw, wv1, soff, lds0 + CW_RING + s * CW_WST + wave * 2048 + 1024);
+    };
+    issue_w(0, 0);
+    issue_w(1, 1);
+    issue_w(2, 2);
+    if (tid < 16) *reinterpret_cast<uint4 *>(smem + CW_ZERO + tid * 16) = uint4{0u, 0u, 0u, 0u};
+
+    // ---- consumer addressing: lane = (r, q): row r of a 16-row fragment, k quarter q (as ctw16_kernel)
+    const int r = lane & 15, q = lane >> 4;
+    const int rh = r >> 3, rw = r & 7;
+    if (tid >= 64 && tid < 128) {
+        const int ch = tid - 64;
+        *reinterpret_cast<float *>(smem + CW_SS + ch * 4) = scale ? scale[ch] : 1.f;
+        *reinterpret_cast<float *>(smem + CW_SS + 256 + ch * 4) = shift ? shift[ch] : 0.f;
+    }
+    cw_wait_vm<0>();
+    __syncthreads();
+    // folded BatchNorm of this lane's channels 16 cot + 4 q .. + 3 for the channel-tile pair the epilogue is working on (cot = 2 c2,
+    // 2 c2 + 1): re-read from LDS when the pair changes (twice per parity), by reads that the next k-step boundary's wait covers
+    u32x4 bss[4];                                    // scale[2 c2], scale[2 c2 + 1], shift[2 c2], shift[2 c2 + 1]
+    const unsigned ssa = lds0 + CW_SS + q * 16;
+    auto load_ss = [](auto c2_c, u32x4(&d)[4], unsigned a) {     // (asm operands must be parameters of a generic lambda, not captures)
+        constexpr int C2 = decltype(c2_c)::value;
+        C4_RD(d[0], a, C2 * 128);
+        C4_RD(d[1], a, C2 * 128 + 64);
+        C4_RD(d[2], a, 256 + C2 * 128);
+        C4_RD(d[3], a, 256 + C2 * 128 + 64);
+    };
+    load_ss(std::integral_constant<int, 0>{}, bss, ssa);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bss[0]), "+v"(bss[1]), "+v"(bss[2]), "+v"(bss[3]) : : "memory");
+
+    const unsigned wl = lds0 + CW_RING + r * 128 + ((q ^ ((r >> 1) & 7)) << 4);        // + stage, + 2048 cot, ^ (k-step << 6)
+    const unsigned R0 = lds0 + (unsigned)((wave * 128 + r) << 8);                      // this lane's own cell, cell tile 0
+    const unsigned ZR = lds0 + CW_ZERO;
+    // ---- fragment row addresses of a tap.  Tile ct = plane 2 wave + (ct >> 2), h-rows 2 (ct & 3) + rh; tap A = (ad, ah, aw) of parity
+    // (pd, ph, pw) reads cell + (dd, dh, dw), d* = p* - a*.  What depends on the lane is small and fixed per PARITY: the w shift has two
+    // values (key and validity of column rw + dw), and an h shift can leave the grid only in one tile class (dh = -1 in tiles with
+    // (ct & 3) == 0, lanes rh == 0; dh = +1 in tiles with (ct & 3) == 3, lanes rh == 1).  So a parity prepares, per aw, R0 ^ key,
+    // ZR ^ key and two lane predicates (the compiler keeps them as scalar masks); a (tap, tile) is then ONE add of a wave-uniform
+    // byte shift and ONE select.
+    unsigned tr0[2], tzr[2];
+    bool tokw[2], tokwh[2];
+    auto parity_setup = [&](int ph, int pw) {
+#pragma unroll
+        for (int aw = 0; aw < 2; ++aw) {
+            const int dw = pw - aw;
+            const unsigned key = ((unsigned)((2 * (rw + dw)) ^ q) & 15u) << 4;
+            tr0[aw] = R0 ^ key;
+            tzr[aw] = ZR ^ key;
+            tokw[aw] = (unsigned)(rw + dw) < 8u;
+            tokwh[aw] = tokw[aw] & (ph ? rh == 0 : rh == 1);      // ... and the lane's h-row stays inside in the special tile class
+        }
+    };
+    auto tap_setup2 = [&](auto a_c, auto ct0_c, int pd, int ph, int pw, unsigned (&t)[8]) {
+        constexpr int A = decltype(a_c)::value, CT0 = decltype(ct0_c)::value, AD = (A >> 2) & 1, AH = (A >> 1) & 1, AW = A & 1;
+        const int dd = pd - AD, dh = ph - AH, dw = pw - AW;
+        const int sft = (dd * 64 + dh * 8 + dw) << 8;                     // wave-uniform
+#pragma unroll
+        for (int ct = CT0; ct < CT0 + 2; ++ct) {
+            const bool plane = (unsigned)(2 * wave + (ct >> 2) + dd) < 8u;                                        // wave-uniform
+            const bool special = ph ? (AH == 0 && (ct & 3) == 3) : (AH == 1 && (ct & 3) == 0);                    // wave-uniform
+            const bool ok = (special ? tokwh[AW] : tokw[AW]) & plane;
+            t[ct] = ok ? tr0[AW] + (unsigned)(sft + ct * 4096) : tzr[AW];
+        }
+    };
+    auto tap_setup = [&](auto a_c, int pd, int ph, int pw, unsigned (&t)[8]) {
+        tap_setup2(a_c, std::integral_constant<int, 0>{}, pd, ph, pw, t);
+        tap_setup2(a_c, std::integral_constant<int, 2>{}, pd, ph, pw, t);
+        tap_setup2(a_c, std::integral_constant<int, 4>{}, pd, ph, pw, t);
+        tap_setup2(a_c, std::integral_constant<int, 6>{}, pd, ph, pw, t);
+    };
+
+    f32x4 accA[4][8], accB[4][8];                    // [cot][ct]; a parity accumulates into one set while the other is written out
+    u32x4 P[12], Q[12];                              // fragments: [0..7] x cell tiles, [8..11] weight channel tiles
+    unsigned ua[8], ub[8];
+    unsigned ws = wl;
+    int stg = 0, cw = 3;
+
+    // ---- the epilogue of one output unit U = (c2, ct) of the PREVIOUS parity (accumulator set PREV) as a program of 32 GAPS, two
+    // INDEPENDENT instructions per gap.  One wave alone overlaps about two simple VALU instructions with a 16x16x32 MFMA, and a dependent
+    // pair in one gap stalls (profiles/microbench/issue_model.hip: 2 v_add per gap free, the third + 4 cycles, a v_xor feeding the
+    // ds_read behind it + 9).  So the unit's two accumulators (h = 0, 1: channel tiles 2 c2 + h) are two streams that advance one
+    // stage per gap, side by side; a stream's next stage reads what its previous gap wrote.  Element e of stream h is value e of
+    // accumulator [2 c2 + h][ct]: channel 16 (2 c2 + h) + 4 q + e of cell 16 ct + r.  Stages of an element (the arithmetic of
+    // vv_bn_act4, in its order): fma | min | * log2 e | exp2 | - 1 | max | +.  Gaps 0..27: 4 elements x 7 stages; 28, 29: bf16 packs;
+    // 30: the two lane swaps; 31: the 16-byte store.
+    // The accumulators live in AGPRs (both sets: all 256 of them) and come out through v_accvgpr_read, written as asm with an "a"
+    // operand: left to itself the allocator keeps one set in VGPRs (VALU instructions read it directly) and spills what no longer fits.
+    // A unit's 8 values are read in the pack / swap / store gaps of the unit BEFORE it (2 per gap); unit 0 reads its own in stage 0.
+    float st_t[2] = {0.f, 0.f}, st_m[2] = {0.f, 0.f}, st_u[2] = {0.f, 0.f}, st_r[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float av[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#define C4_ACCRD(D, SRC) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(D) : "a"(SRC))
+    u32x2 eo[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+    unsigned yvo = 0;                                // this lane's byte offset inside the sample's output for the previous parity
+    auto epi_gap = [&](auto &PREV, auto u_c, auto g_c, auto tail_c) {
+        constexpr int U = decltype(u_c)::value, G = decltype(g_c)::value, C2 = U >> 3, CT = U & 7;
+        constexpr bool TAIL = decltype(tail_c)::value;      // the last parity's epilogue, on its own after the loop
+        if constexpr (G < 28) {
+            constexpr int E = G / 7, S = G % 7;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (S == 0) {
+                    if constexpr (U == 0) C4_ACCRD(av[h][E], PREV[2 * C2 + h][CT][E]);
+                    st_t[h] = __builtin_fmaf(av[h][E], __builtin_bit_cast(f32x4, bss[h])[E], __builtin_bit_cast(f32x4, bss[2 + h])[E]);
+                } else if constexpr (ACT == VV_ACT_ELU && !((C4_ABL & 32) && S < 6) && !((C4_ABL & 128) && S == 3)) {
+                    if constexpr (S == 1) st_m[h] = fminf(st_t[h], 0.f);
+                    else if constexpr (S == 2) st_m[h] = st_m[h] * 1.4426950408889634f;
+                    else if constexpr (S == 3) st_m[h] = __builtin_amdgcn_exp2f(st_m[h]);
+                    else if constexpr (S == 4) st_m[h] = st_m[h] - 1.f;
+                    else if constexpr (S == 5) st_u[h] = fmaxf(st_t[h], 0.f);
+                    else st_r[h][E] = st_u[h] + st_m[h];
+                } else if constexpr (S == 6) {
+                    if (ACT == VV_ACT_RELU) st_r[h][E] = fmaxf(st_t[h], 0.f);
+                    else if (ACT == VV_ACT_LRELU) st_r[h][E] = st_t[h] > 0.f ? st_t[h] : 0.3f * st_t[h];
+                    else st_r[h][E] = st_t[h];
+                }
+            }
+        }
+        if constexpr (G >= 28 && (C4_ABL & 64)) {
+            if constexpr (G == 31) { eo[0][0] ^= __builtin_bit_cast(unsigned, st_r[0][0] + st_r[0][1] + st_r[0][2] + st_r[0][3]); eo[1][1] ^= __builtin_bit_cast(unsigned, st_r[1][0] + st_r[1][1] + st_r[1][2] + st_r[1][3] + av[0][0] + av[1][1]); }
+        } else
+        if constexpr (G >= 28 && U < 15) {           // the NEXT unit's accumulator values, two per gap
+            constexpr int UN = U + 1, E = G - 28;
+            C4_ACCRD(av[0][E], PREV[2 * (UN >> 3)][UN & 7][E]);
+            C4_ACCRD(av[1][E], PREV[2 * (UN >> 3) + 1][UN & 7][E]);
+        }
+        if constexpr (C4_ABL & 64) {
+        } else if constexpr (G == 28 || G == 29) {   // pack values (0, 1) / (2, 3) of both accumulators
+            constexpr int e0 = 2 * (G - 28);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                const bf16x2 v = {static_cast<__bf16>(st_r[h][e0]), static_cast<__bf16>(st_r[h][e0 + 1])};
+                eo[h][G - 28] = __builtin_bit_cast(unsigned, v);
+            }
+        } else if constexpr (G == 30) {              // odd 16-lane rows of the first operand swap with the even rows of the second
+            auto rx = __builtin_amdgcn_permlane16_swap(eo[0][0], eo[1][0], false, false);
+            auto ry = __builtin_amdgcn_permlane16_swap(eo[0][1], eo[1][1], false, false);
+            eo[0] = u32x2{rx[0], ry[0]};
+            eo[1] = u32x2{rx[1], ry[1]};
+        } else if constexpr (G == 31) {
+            constexpr int UO = (CT >> 2) * (2 * 16 * 16 * 128) + (CT & 3) * (4 * 16 * 128) + C2 * 64;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{eo[0][0], eo[0][1], eo[1][0], eo[1][1]}, rsy, yvo, UO, 0);
+            // the next unit works on the other channel-tile pair.  Riding along with the MFMAs, the next k-step boundary's lgkmcnt(0) covers
+            // these reads; in the tail nothing else waits (and after its last unit nothing reads them: a dead look-ahead is not issued)
+            if constexpr (CT == 7 && !(TAIL && C2 == 1)) {
+                load_ss(std::integral_constant<int, 1 - C2>{}, bss, ssa);
+                if constexpr (TAIL) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bss[0]), "+v"(bss[1]), "+v"(bss[2]), "+v"(bss[3]) : : "memory");
+            }
+        }
+    };
+    auto set_yvo = [&](int p) {
+        const int pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        yvo = (unsigned)(((((4 * wave + pd) * 16 + 2 * rh + ph) * 16 + 2 * rw + pw) * 128) + (q & 1) * 32 + (q >> 1) * 16);
+    };
+
+    // ---- one 32-deep k-step: 32 MFMAs of fragments F into ACC.  Gap 0 prepares the first read address; gaps 1..12 hold one fragment read
+    // each (into G, for the next k-step) next to the address arithmetic of the read AFTER it -- never the read's own; gaps 13..31 are
+    // `slot(0..18)`
+    auto kstep = [&](auto &ACC, u32x4(&F)[12], u32x4(&G)[12], const unsigned(&xa)[8], auto kx_c, unsigned wa, auto first_c, auto &&slot) {
+        constexpr unsigned KX = (unsigned)decltype(kx_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        unsigned ra[2] = {0u, 0u};
+        c4_static_for<32>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value, cot = i >> 3, ct = i & 7;
+            if constexpr (C4_ABL & 16) {
+                if constexpr (FIRST) ACC[cot][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if constexpr (FIRST)
+                ACC[cot][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[8 + cot]), *reinterpret_cast<const bf16x8 *>(&F[ct]),
+                                                                       f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            else
+                ACC[cot][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[8 + cot]), *reinterpret_cast<const bf16x8 *>(&F[ct]),
+                                                                       ACC[cot][ct], 0, 0, 0);
+            C4_SB;
+            if constexpr (C4_ABL & 8) {
+            } else if constexpr (i <= 12) {
+                if constexpr (i >= 1 && i <= 8) C4_RD(G[i - 1], ra[(i - 1) & 1], 0);
+                else if constexpr (i >= 9) C4_RD(G[i - 1], wa, (i - 9) * 2048);
+                if constexpr (i < 8) ra[i & 1] = xa[i] ^ KX;
+            }
+            if constexpr (i >= 13) slot(std::integral_constant<int, i - 13>{});
+            C4_SB;
+        });
+    };
+
+    // ---- one parity: 16 chunks (tap x K half) of two k-steps.  SET: accumulator set; EPI: the previous parity's epilogue rides along
+    auto parity_body = [&](auto set_c, auto epi_c, int pi) {
+        constexpr int SET = decltype(set_c)::value;
+        constexpr bool EPI = decltype(epi_c)::value;
+        auto &ACC = *(SET ? &accB : &accA);
+        auto &PREV = *(SET ? &accA : &accB);
+        const int p = p0 + pi, pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
+        const int pn = p + 1, pnd = (pn >> 2) & 1, pnh = (pn >> 1) & 1, pnw = pn & 1;
+        if (EPI) set_yvo(p - 1);
+        c4_static_for<16>([&](auto j_c) {
+            constexpr int J = decltype(j_c)::value, A = J >> 1, KH = J & 1;
+            // k-step 0 (fragments P) | reads of k-step 1 into Q | epilogue gaps 0..18 of unit J
+            C4_WAIT(P);
+            C4_SB;
+            kstep(ACC, P, Q, ua, std::integral_constant<int, KH ? 192 : 64>{}, ws ^ 64u, std::integral_constant<bool, J == 0>{}, [&](auto sl_c) {
+                if constexpr (EPI && !(C4_ABL & 1)) epi_gap(PREV, j_c, sl_c, std::false_type{});
+            });
+            C4_WAIT(Q);
+            // the next chunk's two pieces have landed: younger than them are this wave's two pieces of the chunk after it and, with the
+            // epilogue riding along, one store per chunk (two since).  A smaller count is always safe; the first two chunks of a parity
+            // follow chunks whose store count differs, so they take the strict form.  voxvae/isa_lint.py pins what a piece survives.
+            if (EPI && J >= 2 && !(C4_ABL & 1)) cw_wait_vm<4>();
+            else cw_wait_vm<2>();
+            if constexpr (!(C4_ABL & 2)) __builtin_amdgcn_s_barrier();
+            C4_SB;
+            if constexpr (!(C4_ABL & 4)) issue_w(cw, stg);
+            ++cw;
+            stg = stg == CW_NST - 1 ? 0 : stg + 1;
+            ws = wl + stg * CW_WST;
+            if (KH == 1) {
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) ua[ct] = ub[ct];
+            }
+            C4_SB;
+            // k-step 1 (fragments Q) | reads of the next chunk's k-step 0 into P | epilogue gaps 19..31, then the next tap's addresses
+            kstep(ACC, Q, P, ua, std::integral_constant<int, KH ? 0 : 128>{}, ws, std::false_type{}, [&](auto sl_c) {
+                constexpr int sl = decltype(sl_c)::value;
+                if constexpr (EPI && sl < 13 && !(C4_ABL & 1)) epi_gap(PREV, j_c, std::integral_constant<int, 19 + sl>{}, std::false_type{});
+                if constexpr (KH == 0 && sl >= 13 && sl < 17) {         // next tap's row addresses, two cell tiles per gap
+                    if constexpr (A < 7) {
+                        tap_setup2(std::integral_constant<int, (A + 1) & 7>{}, std::integral_constant<int, 2 * (sl - 13)>{}, pd, ph, pw, ub);
+                    } else {                                            // the last tap's chunk prepares the NEXT parity's first tap
+                        if constexpr (sl == 13) parity_setup(pnh, pnw);
+                        tap_setup2(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * (sl - 13)>{}, pnd, pnh, pnw, ub);
+                    }
+                }
+            });
+        });
+    };
+
+    parity_setup((p0 >> 1) & 1, p0 & 1);
+    tap_setup(std::integral_constant<int, 0>{}, (p0 >> 2) & 1, (p0 >> 1) & 1, p0 & 1, ua);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) C4_RD(P[k], ua[k], 0);
+    C4_RD(P[8], ws, 0);
+    C4_RD(P[9], ws, 2048);
+    C4_RD(P[10], ws, 4096);
+    C4_RD(P[11], ws, 6144);
+    parity_body(std::integral_constant<int, 0>{}, std::false_type{}, 0);
+#pragma unroll 1
+    for (int pi = 1; pi < npar; pi += 2) {
+        parity_body(std::integral_constant<int, 1>{}, std::true_type{}, pi);
+        if (pi + 1 < npar) parity_body(std::integral_constant<int, 0>{}, std::true_type{}, pi + 1);
+    }
+    C4_WAIT(P);                                      // the look-ahead reads of the chunk after the last
+    // the last parity's epilogue, on its own
+    set_yvo(p0 + npar - 1);
+    if ((npar - 1) & 1) {
+        c4_static_for<16>([&](auto u_c) { c4_static_for<32>([&](auto k_c) { epi_gap(accB, u_c, k_c, std::true_type{}); }); });
+    } else {
+        c4_static_for<16>([&](auto u_c) { c4_static_for<32>([&](auto k_c) { epi_gap(accA, u_c, k_c, std::true_type{}); }); });
+    }
+    cw_wait_vm<0>();                                 // the tail's pieces still target this workgroup's LDS
+}
+
 }  // namespace
 
 VV_EXPORT int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype) {
@@ -475,18 +801,25 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
     }
-    const char *se = vv_hook("VV_CTW_SHAPE");        // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
-    const bool shape16 = !se || atoi(se) != 32;
+    // VV_CTW_SHAPE (test hook): 4 = four waves / one per SIMD / epilogue in the MFMA gaps (default), 16 = the eight-wave kernel on
+    // v_mfma_f32_16x16x32_bf16, 32 = the eight-wave kernel on v_mfma_f32_32x32x16_bf16
+    const char *se = vv_hook("VV_CTW_SHAPE");
+    const int shape = se ? atoi(se) : 4;
+    const bool shape16 = shape != 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto launch = [&](auto act_c) {
         constexpr int ACT = decltype(act_c)::value;
         static const bool attr = [] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw16_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw4_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
             return true;
         }();
         (void)attr;
-        if (shape16)
+        if (shape != 16 && shape != 32)
+            VV_LAUNCH(ctw4_kernel<ACT>, dim3((unsigned)batch * ps), dim3(256), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
+                      reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps);
+        else if (shape16)
             VV_LAUNCH(ctw16_kernel<ACT>, dim3((unsigned)batch * ps), dim3(512), CW_LDS, st, reinterpret_cast<const __bf16 *>(x),
                       reinterpret_cast<const __bf16 *>(w_skip), scale, shift, reinterpret_cast<__bf16 *>(y), 8 / ps);
         else

@@ -20,6 +20,14 @@ LIB_HOOKS = os.path.join(LIBDIR, 'libvoxvae_hooks.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function', '-Wno-shift-op-parentheses']
 HOOK_FLAG = '-DVV_TEST_HOOKS'
+# per-source code-generation flags.  convt_whole.hip: the four-wave kernel places its epilogue piece by piece between MFMAs; the SLP
+# vectoriser pairs up operations of different pieces into v_pk_* instructions (an anti-lever beside MFMAs, MI355X_MICROARCH.md) and piles the work
+# up in one gap
+EXTRA_FLAGS = {'convt_whole.hip': ['-fno-slp-vectorize']}
+
+
+def flags_for(src, hooks=False):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ([HOOK_FLAG] if hooks else [])
 
 
 def sources():
@@ -73,13 +81,15 @@ def build(force=False, verbose=False, lint=True):
         base = os.path.basename(src)[:-4]
         obj = os.path.join(LIBDIR, base + '.o')
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append(([HIPCC] + FLAGS + ['-c', src, '-o', obj], obj, [src] + hdrs, FLAGS))
+        fl = flags_for(src)
+        if force or _stale(obj, [src] + hdrs, fl):
+            jobs.append(([HIPCC] + fl + ['-c', src, '-o', obj], obj, [src] + hdrs, fl))
         if _uses_hooks(src):
             hobj = os.path.join(LIBDIR, 'hooks', base + '.o')
             hobjs.append(hobj)
-            if force or _stale(hobj, [src] + hdrs, hflags):
-                jobs.append(([HIPCC] + hflags + ['-c', src, '-o', hobj], hobj, [src] + hdrs, hflags))
+            hfl = flags_for(src, True)
+            if force or _stale(hobj, [src] + hdrs, hfl):
+                jobs.append(([HIPCC] + hfl + ['-c', src, '-o', hobj], hobj, [src] + hdrs, hfl))
         else:
             hobjs.append(obj)
 

@@ -49,11 +49,13 @@ def compile_isa(src, force=False):
     for p in deps:
         with open(p, 'rb') as f:
             h.update(f.read())
-    stamp = h.hexdigest() + ' ' + ' '.join(FLAGS)
+    from . import build as _build
+    flags = FLAGS + _build.EXTRA_FLAGS.get(os.path.basename(src), [])
+    stamp = h.hexdigest() + ' ' + ' '.join(flags)
     sp = out + '.srchash'
     if not force and os.path.exists(out) and os.path.exists(sp) and open(sp).read() == stamp:
         return out
-    subprocess.check_call([HIPCC] + FLAGS + ['--offload-device-only', '-S', src, '-o', out], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC] + flags + ['--offload-device-only', '-S', src, '-o', out], stderr=subprocess.DEVNULL)
     with open(sp, 'w') as f:
         f.write(stamp)
     return out
@@ -256,7 +258,7 @@ def lint_file(src):
 PINNED_WAITS = {
     'conv_direct_kernel': (2, 2), 'conv_direct16_kernel': (2, 2), 'conv_direct_fp8_kernel': (2, 2),
     'convT_direct_kernel': (1, 2), 'convT_direct_fp8_kernel': (1, 2),
-    'ctw_kernel': (4, 2), 'ctw16_kernel': (4, 2),
+    'ctw_kernel': (4, 2), 'ctw16_kernel': (4, 2), 'ctw4_kernel': (4, 2),
     'final_bce_sweep_kernel': (3, 0), 'final_bce_sweepw_kernel': (3, 0), 'final_bce_sweep_fp8_kernel': (3, 0), 'final_bce_mfma_kernel': (0, 0),
     'igemm_kernel': (None, 0), 'pg_kernel': (None, 2), 'lt_e5_kernel': (1, 0),
     'sd_kernel': (2, 2), 'wgrad_bf16_kernel': (1, 1), 'wgrad_phase_kernel': (1, 2),

@@ -26,8 +26,8 @@ streams = [torch.cuda.Stream() for _ in range(2)]
 sp = [ctypes.c_void_p(s.cuda_stream) for s in streams]
 N = 400
 for rnd in range(2):
-    for kind in ('halo', 'whole32', 'whole16'):
-        os.environ['VV_CTW_SHAPE'] = '32' if kind == 'whole32' else '16'
+    for kind in ('halo', 'whole32', 'whole16', 'whole4'):
+        os.environ['VV_CTW_SHAPE'] = kind[5:] if kind != 'halo' else '16'
         for ns in (1, 2):
             for i in range(20):
                 launch(kind, i % ns, sp[i % ns])

@@ -138,7 +138,7 @@ def test_convT3d_k4s2_skip(L, B, cin, cout, act):
 
 # whole-sample transposed convolution 8^3 x 128 -> 16^3 x 64 (convt_whole.hip): every parity split, every activation,
 # batches that are not a multiple of anything, null scale / shift; compared against the float64 definition
-@pytest.mark.parametrize('shape', [16, 32])            # MFMA shape: 16x16x32 (default) / 32x32x16
+@pytest.mark.parametrize('shape', [4, 16, 32])         # 4: four waves, one per SIMD, epilogue in the MFMA gaps (default); 16 / 32: the eight-wave kernel, MFMA 16x16x32 / 32x32x16
 @pytest.mark.parametrize('ps', [0, 1, 2, 4, 8])
 @pytest.mark.parametrize('B,act', [(3, 1), (7, 0), (33, 2), (5, 3)])
 def test_convT3d_k4s2_whole(L, B, act, ps, shape, monkeypatch):
@@ -735,7 +735,7 @@ def test_widest_layers_full_batch_forms_agree(L, monkeypatch):
     L.call('vv_pack_convT_k4s2_skip', L.ptr(w), L.ptr(wk), 128, 64, _st())
     y0 = torch.full((B, 16, 16, 16, 64), float('nan'), dtype=torch.bfloat16, device=DEV)
     L.call('vv_convT3d_k4s2_direct_fwd', L.ptr(x), L.ptr(wf), L.ptr(sc), L.ptr(sh), L.ptr(y0), B, 8, 128, 64, 1, L.VV_BF16, _st())
-    for shape in ('16', '32'):
+    for shape in ('4', '16', '32'):
         for ps in ('1', '2'):
             monkeypatch.setenv('VV_CTW_SHAPE', shape)
             monkeypatch.setenv('VV_CTW_PS', ps)
