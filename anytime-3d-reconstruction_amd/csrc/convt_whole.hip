@@ -615,6 +615,12 @@ __global__ __launch_bounds__(256, 1) void ctw4_kernel(const __bf16 *__restrict__
     auto epi_gap = [&](auto &PREV, auto u_c, auto g_c, auto tail_c) {
         constexpr int U = decltype(u_c)::value, G = decltype(g_c)::value, C2 = U >> 3, CT = U & 7;
         constexpr bool TAIL = decltype(tail_c)::value;      // the last parity's epilogue, on its own after the loop
+        if constexpr (G < 28 && (C4_ABL & 512)) {    // diagnostic: the same number of VALU instructions as plain asm v_fma on two private registers
+            constexpr int E = G / 7, S = G % 7;
+            if constexpr (S == 0) { st_r[0][E] = av[0][E]; st_r[1][E] = av[1][E]; }
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(st_t[0]) : "v"(st_u[0]), "v"(st_u[1]));
+            asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(st_t[1]) : "v"(st_u[0]), "v"(st_u[1]));
+        } else
         if constexpr (G < 28) {
             constexpr int E = G / 7, S = G % 7;
 #pragma unroll
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(256, 1) void ctw4_kernel(const __bf16 *__restrict__
     cw_wait_vm<0>();                                 // the tail's pieces still target this workgroup's LDS
 }
 
+
 }  // namespace
 
 VV_EXPORT int vv_convT3d_k4s2_whole_supported(int side, int cin, int cout, int dtype) {
@@ -801,10 +808,10 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) ps = v;
     }
-    // VV_CTW_SHAPE (test hook): 4 = four waves / one per SIMD / epilogue in the MFMA gaps (default), 16 = the eight-wave kernel on
-    // v_mfma_f32_16x16x32_bf16, 32 = the eight-wave kernel on v_mfma_f32_32x32x16_bf16
+    // VV_CTW_SHAPE (test hook): 16 = the eight-wave kernel on v_mfma_f32_16x16x32_bf16 (default), 32 = the eight-wave kernel on
+    // v_mfma_f32_32x32x16_bf16, 4 = four waves / one per SIMD / epilogue in the MFMA gaps on 16x16x32 (measured slower)
     const char *se = vv_hook("VV_CTW_SHAPE");
-    const int shape = se ? atoi(se) : 4;
+    const int shape = se ? atoi(se) : 16;
     const bool shape16 = shape != 32;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto launch = [&](auto act_c) {

@@ -22,7 +22,7 @@ for n in names:
     else:
         libs[n] = ctypes.CDLL(os.path.join(_R, 'scratch/abl/libc4_%s.so' % n))
 def launch(n):
-    os.environ['VV_CTW_SHAPE'] = n[4:] if n.startswith('tree') else '4'
+    os.environ['VV_CTW_SHAPE'] = n[4:] if n.startswith('tree') else os.environ.get('C4_SHAPE', '4')
     f = libs[n].vv_convT3d_k4s2_whole_fwd; f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
     rc = f(L.ptr(x), L.ptr(wk), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 8, cin, cout, 1, L.VV_BF16, cs)
