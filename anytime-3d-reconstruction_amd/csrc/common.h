@@ -167,3 +167,9 @@ void vv_wgrad_phase_launch(const void *src, const void *g, float *slabs, int bat
 // final_bce_fp8.hip (internal): sweep-form last layer with an e4m3fn input; returns the partial blocks per sample.
 int vv_final_bce_sweep_fp8_launch(const void *x, const float *w_keras, const float *target, float *probs, float *logits, float *partials,
                                   int batch, int side, float gamma, float epsilon, hipStream_t st);
+
+// posgemm.hip (internal): the 4^3 -> 2^3 convolution written as float32 split-K slabs only; slab of (position p, share s, sample
+// tile mt) = ws + ((first[p] + s) * mtiles + mt) * rows_per_tile * cout floats, rows = samples of the tile, cout floats per row.
+struct VvPgSlabPlan { int npos, mtiles, nitems, rows_per_tile; unsigned char nsplit[8]; unsigned short first[8]; };
+size_t vv_pg_conv_slab_bytes(int batch, int cin, int cout);
+int vv_pg_conv_slabs(const void *x, const void *w, int batch, int cin, int cout, void *ws, size_t ws_bytes, hipStream_t st, VvPgSlabPlan *plan);

@@ -289,6 +289,107 @@ __global__ __launch_bounds__(256) void lt_mid_kernel(const LtMidArgs a) {
     });
 }
 
+
+// ---- round 4: the 4^3 -> 2^3 convolution's split-K slabs summed HERE instead of by a reduce launch (posgemm.hip writes slabs only:
+// vv_pg_conv_slabs).  Workgroup = 16 samples x one output position p of that layer x 256 of its channels = one K slice of the
+// encoder-tail GEMM: the threads sum the position's shares in share order (what pg_reduce_kernel does, same order, same sums), apply the
+// layer's folded BN + activation, round to bf16 (the value the unfused path stores) and leave the [16][256] tile in LDS as the MFMA
+// operand; the tile meets its [E][256] slice of the tail panel (fragments straight from global memory, in flight since the first
+// instruction) on v_mfma_f32_16x16x32_bf16 and goes out as the float32 slab [slice][B][E] that lt_mid_kernel sums.  The convolution's
+// output never exists in memory, its reduce launch and lt_e5_kernel's staging round trip are gone.
+struct LtE5xArgs {
+    const float *pslabs;      // posgemm slabs
+    const float *scale4, *shift4;
+    const void *w5;           // [E][K5] bf16, K5 = 8 * cout4
+    float *slabs;             // [8 * nh][B][E]
+    int batch, cout4, E, nh, mtiles, rows_per_tile, act;
+    unsigned char nsplit[8];
+    unsigned short first[8];
+};
+
+constexpr int LTX_PITCH = 512 + 16;      // bytes per row of the [16][256] bf16 tile (16-byte pad: rows 4 banks apart)
+
+template <int ACT>
+__global__ __launch_bounds__(256) void lt_e5x_kernel(const LtE5xArgs a) {
+    __shared__ __attribute__((aligned(16))) char xs[16 * LTX_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = 8 * a.nh;
+    const int sb = blockIdx.x / per, rem = blockIdx.x - sb * per;
+    const int p = rem / a.nh, chh = rem - p * a.nh;
+    const int b0 = sb * 16;
+    const int K5 = 8 * a.cout4;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int ntile = a.E >> 4;                          // 16-column tiles of the tail's output, tile wave + 4 i to this wave
+
+    // weight fragments of this wave's (<= 2) output tiles, 8 k-steps of 32: W5[t*16 + r16][p*cout4 + chh*256 + ks*32 + kq*8 ..]
+    uint4 wf[2][8];
+    {
+        const __bf16 *w5 = reinterpret_cast<const __bf16 *>(a.w5);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                wf[i][ks] = t < ntile ? *reinterpret_cast<const uint4 *>(w5 + (size_t)(t * 16 + r16) * K5 + p * a.cout4 + chh * 256 + ks * 32 + kq * 8)
+                                      : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // ---- the tile: thread = (row tid >> 4, channel quads (tid & 15) * 4 + 64 j, j = 0..3: the 16 lanes of a row read 256 contiguous
+    // bytes per load): shares summed in order, BN, activation, bf16
+    {
+        const int r = tid >> 4, cg = tid & 15;
+        const int b = b0 + r;
+        const bool live = b < a.batch;
+        const int mt = b0 / a.rows_per_tile, rl = b - mt * a.rows_per_tile;
+        const int c0 = chh * 256 + cg * 4;
+        const int ns = a.nsplit[p];
+        const float *src = a.pslabs + (((size_t)a.first[p] * a.mtiles + mt) * a.rows_per_tile + (live ? rl : 0)) * a.cout4 + c0;
+        const size_t sstride = (size_t)a.mtiles * a.rows_per_tile * a.cout4;
+        f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int s0 = 0; s0 < ns; s0 += 4) {             // 16 independent 16-byte loads in flight per trip
+            f32x4 v[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[k][j] = (live && s0 + k < ns) ? *reinterpret_cast<const f32x4 *>(src + (size_t)(s0 + k) * sstride + j * 64) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[k][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (a.scale4) sc = *reinterpret_cast<const f32x4 *>(a.scale4 + c0 + j * 64);
+            if (a.shift4) sh = *reinterpret_cast<const f32x4 *>(a.shift4 + c0 + j * 64);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(live ? lt_act<ACT>(s[j][e] * sc[e] + sh[e]) : 0.f);
+            *reinterpret_cast<bf16x4 *>(xs + r * LTX_PITCH + (j * 64 + cg * 4) * 2) = o;
+        }
+    }
+    __syncthreads();
+    // ---- [16][256] x [256][E]: weights first (D[n][row]): lane (r16, kq) ends with outputs t*16 + 4 kq .. + 3 of row r16
+    f32x4 c[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const uint4 xf = *reinterpret_cast<const uint4 *>(xs + r16 * LTX_PITCH + ks * 64 + kq * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&wf[i][ks]), *reinterpret_cast<const bf16x8 *>(&xf), c[i], 0, 0, 0);
+    }
+    if (b0 + r16 < a.batch) {
+        float *dst = a.slabs + ((size_t)(p * a.nh + chh) * a.batch + b0 + r16) * a.E;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+            if (t < ntile) *reinterpret_cast<f32x4 *>(dst + t * 16 + kq * 4) = c[i];
+        }
+    }
+}
+
 struct LtPlan { int kslice, nslice, nq; size_t ws; };
 
 LtPlan lt_plan(int batch, int K5, int E, int n1) {
@@ -305,6 +406,24 @@ LtPlan lt_plan(int batch, int K5, int E, int n1) {
         if (n1 % (16 * c) == 0) { p.nq = c; break; }
     p.ws = (size_t)p.nslice * batch * E * sizeof(float);
     return p;
+}
+
+int lt_launch_mid(const float *slabs, int nslice, int nq, const float *e5_scale, const float *eps, const void *wd, const float *scale_d,
+                  const float *shift_d, const void *w1, const float *scale_1, const float *shift_1, float *enc_out, float *z, void *z_act, float *kl,
+                  void *h1, int batch, int E, int L, int lin, int n1, int variational, int act, hipStream_t st) {
+    LtMidArgs m;
+    m.slabs = slabs; m.e5_scale = e5_scale; m.eps = eps; m.wd = wd; m.scale_d = scale_d; m.shift_d = shift_d;
+    m.w1 = w1; m.scale_1 = scale_1; m.shift_1 = shift_1; m.enc_out = enc_out; m.z = z; m.z_act = z_act; m.kl = kl; m.h1 = h1;
+    m.batch = batch; m.E = E; m.L = L; m.lin = lin; m.n1 = n1; m.nslice = nslice; m.nq = nq; m.variational = variational; m.act = act;
+    const size_t lds = (size_t)16 * E * 4 + (size_t)16 * L * 2 + (size_t)16 * lin * 2;
+    const dim3 grid(((batch + 15) / 16) * nq);
+    switch (act) {
+        case VV_ACT_ELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_ELU>, grid, dim3(256), lds, st, m); break;
+        case VV_ACT_RELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_RELU>, grid, dim3(256), lds, st, m); break;
+        case VV_ACT_LRELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_LRELU>, grid, dim3(256), lds, st, m); break;
+        default: VV_LAUNCH(lt_mid_kernel<VV_ACT_NONE>, grid, dim3(256), lds, st, m); break;
+    }
+    return vv_launch_status();
 }
 
 }  // namespace
@@ -348,17 +467,61 @@ VV_EXPORT int vv_latent_tail_fwd(const void *h, const void *w5, const float *e5_
     VV_LAUNCH(lt_e5_kernel, dim3(ntn * ntm * p.nslice), dim3(256), LT_E5_LDS, st, a);
     int rc = vv_launch_status();
     if (rc != VV_OK) return rc;
-    LtMidArgs m;
-    m.slabs = a.slabs; m.e5_scale = e5_scale; m.eps = eps; m.wd = wd; m.scale_d = scale_d; m.shift_d = shift_d;
-    m.w1 = w1; m.scale_1 = scale_1; m.shift_1 = shift_1; m.enc_out = enc_out; m.z = z; m.z_act = z_act; m.kl = kl; m.h1 = h1;
-    m.batch = batch; m.E = E; m.L = L; m.lin = lin; m.n1 = n1; m.nslice = p.nslice; m.nq = p.nq; m.variational = variational; m.act = act;
-    const size_t lds = (size_t)16 * E * 4 + (size_t)16 * L * 2 + (size_t)16 * lin * 2;
-    const dim3 grid(((batch + 15) / 16) * p.nq);
+    return lt_launch_mid(a.slabs, p.nslice, p.nq, e5_scale, eps, wd, scale_d, shift_d, w1, scale_1, shift_1, enc_out, z, z_act, kl, h1, batch, E, L, lin,
+                         n1, variational, act, st);
+}
+
+// ---- the 4^3 -> 2^3 convolution + the latent tail in three launches: pg_kernel<0> (slabs) -> lt_e5x_kernel -> lt_mid_kernel
+VV_EXPORT int vv_conv_pos_latent_tail_supported(int cin4, int cout4, int E, int L, int lin, int n1, int variational, int dtype) {
+    if (!vv_latent_tail_supported(8 * cout4, E, L, lin, n1, variational, dtype)) return 0;
+    if (cout4 % 256 || E % 16 || E > 128 || 8 * (cout4 / 256) > 64) return 0;
+    return vv_conv3d_k4s2_pos_supported(4, cin4, cout4, dtype);
+}
+
+VV_EXPORT size_t vv_conv_pos_latent_tail_workspace_bytes(int batch, int cin4, int cout4, int E) {
+    const size_t sl = vv_pg_conv_slab_bytes(batch, cin4, cout4);
+    if (!sl || E <= 0 || cout4 % 256) return 0;
+    return sl + (size_t)8 * (cout4 / 256) * batch * E * sizeof(float);
+}
+
+VV_EXPORT int vv_conv_pos_latent_tail_fwd(const void *x4, const void *w4_skip, const float *scale4, const float *shift4, int cin4, int cout4,
+                                          const void *w5, const float *e5_scale, const float *eps, const void *wd, const float *scale_d,
+                                          const float *shift_d, const void *w1, const float *scale_1, const float *shift_1, float *enc_out,
+                                          float *z, void *z_act, float *kl, void *h1, int batch, int E, int L, int lin, int n1, int variational,
+                                          int act, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x4 || !w4_skip || !w5 || !wd || !w1 || !z || !h1) return VV_ERR_NULL;
+    if (variational && !eps) return VV_ERR_NULL;
+    if (batch <= 0 || !vv_conv_pos_latent_tail_supported(cin4, cout4, E, L, lin, n1, variational, dtype)) return VV_ERR_SHAPE;
+    if ((size_t)E * 8 * cout4 * 2 >= 0xFFFFFFF0ull) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x4) || !vv_aligned16(w4_skip) || !vv_aligned16(w5) || !vv_aligned16(wd) || !vv_aligned16(w1) || !vv_aligned16(h1) ||
+        !vv_aligned16(z) || (enc_out && !vv_aligned16(enc_out)) || (scale4 && !vv_aligned16(scale4)) || (shift4 && !vv_aligned16(shift4)))
+        return VV_ERR_ALIGN;
+    const size_t sl = vv_pg_conv_slab_bytes(batch, cin4, cout4);
+    const int nh = cout4 / 256, nslice = 8 * nh;
+    if (!sl) return VV_ERR_SHAPE;
+    if (!workspace || !vv_aligned16(workspace) || workspace_bytes < sl + (size_t)nslice * batch * E * sizeof(float)) return VV_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    VvPgSlabPlan plan;
+    int rc = vv_pg_conv_slabs(x4, w4_skip, batch, cin4, cout4, workspace, sl, st, &plan);
+    if (rc != VV_OK) return rc;
+    LtE5xArgs a;
+    a.pslabs = reinterpret_cast<const float *>(workspace);
+    a.scale4 = scale4; a.shift4 = shift4; a.w5 = w5;
+    a.slabs = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + sl);
+    a.batch = batch; a.cout4 = cout4; a.E = E; a.nh = nh; a.mtiles = plan.mtiles; a.rows_per_tile = plan.rows_per_tile; a.act = act;
+    for (int p = 0; p < 8; ++p) { a.nsplit[p] = plan.nsplit[p]; a.first[p] = plan.first[p]; }
+    const dim3 grid(((batch + 15) / 16) * nslice);
     switch (act) {
-        case VV_ACT_ELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_ELU>, grid, dim3(256), lds, st, m); break;
-        case VV_ACT_RELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_RELU>, grid, dim3(256), lds, st, m); break;
-        case VV_ACT_LRELU: VV_LAUNCH(lt_mid_kernel<VV_ACT_LRELU>, grid, dim3(256), lds, st, m); break;
-        default: VV_LAUNCH(lt_mid_kernel<VV_ACT_NONE>, grid, dim3(256), lds, st, m); break;
+        case VV_ACT_ELU: VV_LAUNCH(lt_e5x_kernel<VV_ACT_ELU>, grid, dim3(256), 0, st, a); break;
+        case VV_ACT_RELU: VV_LAUNCH(lt_e5x_kernel<VV_ACT_RELU>, grid, dim3(256), 0, st, a); break;
+        case VV_ACT_LRELU: VV_LAUNCH(lt_e5x_kernel<VV_ACT_LRELU>, grid, dim3(256), 0, st, a); break;
+        default: VV_LAUNCH(lt_e5x_kernel<VV_ACT_NONE>, grid, dim3(256), 0, st, a); break;
     }
-    return vv_launch_status();
+    rc = vv_launch_status();
+    if (rc != VV_OK) return rc;
+    int nq = 1;
+    for (int c = 16; c >= 2; c >>= 1)
+        if (n1 % (16 * c) == 0) { nq = c; break; }
+    return lt_launch_mid(a.slabs, nslice, nq, e5_scale, eps, wd, scale_d, shift_d, w1, scale_1, shift_1, enc_out, z, z_act, kl, h1, batch, E, L, lin, n1,
+                         variational, act, st);
 }

@@ -50,6 +50,7 @@ struct PgArgs {
     int batch, cin, cout, act;
     unsigned x_bytes, w_bytes;
     int ntn, mtiles, npos, nitems;     // channel tiles, sample tiles, output positions, sum of shares over the positions
+    int force_slabs;                   // 1: one-share positions write a float32 slab too (the consumer sums / activates: vv_pg_conv_slabs)
     unsigned char nsplit[PG_MAXPOS];   // shares of position p
     unsigned short first[PG_MAXPOS];   // first share slot of position p
 };
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(512, 1) void pg_kernel(const PgArgs a) {
 
     // ---- epilogue.  lane = sample row fr of row tile mt_, registers walk channels (q & 3) + 8 (q >> 2) + 4 fh of channel
     // tile nt_.  One share: folded BN + activation, bf16, the layer's output.  Several: float32 slab.
-    const bool final_out = nshare == 1;
+    const bool final_out = nshare == 1 && !a.force_slabs;
     const int m_rows = a.batch - m0 < PG_BM ? a.batch - m0 : PG_BM;
     auto fill = [&](auto act_c, auto fin_c) {
         constexpr int ACT = decltype(act_c)::value;
@@ -410,6 +411,7 @@ int pg_run(const void *x, const void *w, const float *scale, const float *shift,
         a.w = w; a.scale = scale; a.shift = shift;
         a.slabs = reinterpret_cast<float *>(ws);
         a.batch = nb; a.cin = cin; a.cout = cout; a.act = act;
+        a.force_slabs = 0;
         a.x_bytes = (unsigned)((size_t)nb * sample_in);
         a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
         VV_LAUNCH(pg_kernel<MODE>, dim3(a.nitems * a.ntn * a.mtiles), dim3(512), PG_LDS, st, a);
@@ -438,6 +440,37 @@ bool pg_shape_ok(int cin, int cout) {
 }
 
 }  // namespace
+
+// ---- internal (common.h): the 4^3 -> 2^3 convolution as float32 slabs ONLY -- no reduce launch, no folded BN: the consumer
+// (latent_tail.hip: lt_e5x_kernel) sums the shares of a position in share order, exactly as pg_reduce_kernel does, while it builds
+// its own MFMA operand.  One launch; the whole batch must fit 32-bit buffer offsets.
+size_t vv_pg_conv_slab_bytes(int batch, int cin, int cout) {
+    if (batch <= 0 || !pg_shape_ok(cin, cout) || (size_t)batch * 64 * cin * 2 > 0x7FFFFFFFull) return 0;
+    return pg_ws_bytes<0>(batch, cin, cout);
+}
+
+int vv_pg_conv_slabs(const void *x, const void *w, int batch, int cin, int cout, void *ws, size_t ws_bytes, hipStream_t st, VvPgSlabPlan *plan) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pg_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS);
+        return true;
+    }();
+    (void)attr;
+    const size_t need = vv_pg_conv_slab_bytes(batch, cin, cout);
+    if (!need) return VV_ERR_SHAPE;
+    if (!ws || ws_bytes < need || !vv_aligned16(ws)) return VV_ERR_WORKSPACE;
+    PgArgs a;
+    pg_plan<0>(a, batch, cin, cout);
+    a.x = x; a.y = nullptr; a.w = w; a.scale = nullptr; a.shift = nullptr;
+    a.slabs = reinterpret_cast<float *>(ws);
+    a.batch = batch; a.cin = cin; a.cout = cout; a.act = VV_ACT_NONE;
+    a.force_slabs = 1;
+    a.x_bytes = (unsigned)((size_t)batch * 64 * cin * 2);
+    a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
+    VV_LAUNCH(pg_kernel<0>, dim3(a.nitems * a.ntn * a.mtiles), dim3(512), PG_LDS, st, a);
+    plan->npos = a.npos; plan->mtiles = a.mtiles; plan->nitems = a.nitems; plan->rows_per_tile = PG_BM;
+    for (int p = 0; p < 8; ++p) { plan->nsplit[p] = a.nsplit[p]; plan->first[p] = a.first[p]; }
+    return vv_launch_status();
+}
 
 VV_EXPORT int vv_conv3d_k4s2_pos_supported(int side, int cin, int cout, int dtype) {
     return dtype == VV_BF16 && side == 4 && pg_shape_ok(cin, cout);

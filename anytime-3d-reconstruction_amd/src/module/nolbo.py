@@ -83,13 +83,15 @@ class _ModelnetBase(object):
         missing_prob = 0, eval_forward_device): the fused latent tail when it applies, else the split calls.
         Returns (z, z_act, kl, h1 or None)."""
         if _E.latent_tail_supported(self._enc_eng, self._dec_eng, self._variational):
-            h = self._enc_eng.forward(x, stop_before_tail=True)
+            pos = _E.pos_latent_tail_supported(self._enc_eng, self._dec_eng, self._variational, x.shape[0])
+            h = self._enc_eng.forward(x, stop_before_tail=True, stop_before_pos=pos)
+            pos = pos and h.shape[1] == 4          # the layer in front of the tail was left to the fused call
             if self._variational:
                 Lz = self._latent_dim
                 eps = torch.randn(x.shape[0], Lz, dtype=torch.float32, device=self._device) if eps is None else self._dev(eps)
             else:
                 eps = None
-            z, z_act, kl, _, h1 = _E.latent_tail(self._enc_eng, self._dec_eng, h, eps, self._variational)
+            z, z_act, kl, _, h1 = _E.latent_tail(self._enc_eng, self._dec_eng, h, eps, self._variational, pos_layer=pos)
             return z, z_act, kl, h1
         z, z_act, kl = self._encode_latent(x, eps)
         return z, z_act, kl, None

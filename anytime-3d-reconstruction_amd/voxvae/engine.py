@@ -308,9 +308,12 @@ class EncoderEngine(_EngineBase):
         L.call('vv_pack_conv_k4s1_meanpool', L.ptr(wk), L.ptr(w), self.S, f[i - 1], f[i], L.VV_FP8 if q else self.dt, st)
         self.packed['w%d' % i] = w
 
-    def forward(self, x, stop_before_tail=False):
+    def forward(self, x, stop_before_tail=False, stop_before_pos=False):
         """x: float32 CUDA tensor [B,D,D,D,1] (contiguous) -> enc_out float32 [B,E].
-        stop_before_tail: return the last stride-2 activation [B,S,S,S,C] instead (the fused latent tail consumes it)."""
+        stop_before_tail: return the last stride-2 activation [B,S,S,S,C] instead (the fused latent tail consumes it).
+        stop_before_pos (with stop_before_tail): when the last stride-2 layer is the position-major 4^3 -> 2^3 form, stop in FRONT of it and
+        return its input [B,4,4,4,C]: latent_tail(..., pos_layer=True) runs that layer and the tail as one fused call (its split-K
+        partial sums are summed by the tail's first kernel)."""
         self.ensure_packed()
         B, D, f, pk, st = x.shape[0], self.D, self.filters, self.packed, _stream()
         if tuple(x.shape[1:]) != (D, D, D, 1) or x.dtype != torch.float32 or not x.is_contiguous():
@@ -343,6 +346,8 @@ class EncoderEngine(_EngineBase):
                                L.ptr(o), B, side, f[i - 1], f[i], self.act, L.VV_FP8, odt, L.ptr(ws), ws.numel(), st)
                 hdt = odt
             elif ('ws%d' % i) in pk and not nq:
+                if stop_before_pos and stop_before_tail and side == 4 and i == len(f) - 2 and hdt == self.dt and not pk.get('q%d' % (i + 1), False):
+                    return h
                 o = self._empty(B, side // 2, side // 2, side // 2, f[i])
                 if side == 4:
                     ws = self.ws.get(L.load().vv_conv3d_k4s2_pos_workspace_bytes(B, f[i - 1], f[i]))
@@ -616,8 +621,26 @@ def latent_tail_supported(enc, dec, variational):
         and enc.act == dec.act
 
 
-def latent_tail(enc, dec, h, eps, variational, want_enc_out=False):
+def pos_latent_tail_supported(enc, dec, variational, batch=1):
+    """True when the last stride-2 encoder layer (4^3 -> 2^3, position-major form) and the latent tail can run as ONE fused call
+    (vv_conv_pos_latent_tail_fwd: the layer's split-K partial sums are summed inside the tail; one launch, so the batch's layer
+    input has to fit 32-bit buffer offsets)."""
+    if not latent_tail_supported(enc, dec, variational) or os.environ.get('VV_NO_POS_TAIL') or enc.S != 2 or len(enc.filters) < 3:
+        return False
+    if batch * 64 * enc.filters[-3] * 2 > 0x7FFFFFFF:
+        return False
+    ne = len(enc.filters) - 1
+    enc.ensure_packed()
+    if ('ws%d' % (ne - 1)) not in enc.packed or enc.packed.get('q%d' % (ne - 1), False):
+        return False
+    return bool(L.load().vv_conv_pos_latent_tail_supported(enc.filters[-3], enc.filters[-2], enc.E, dec.L, dec.S ** 3 * dec.ch,
+                                                           dec.S ** 3 * dec.filters[0], int(variational), L.VV_BF16))
+
+
+def latent_tail(enc, dec, h, eps, variational, want_enc_out=False, pos_layer=False):
     """Fused latent tail (vv_latent_tail_fwd): h = EncoderEngine.forward(x, stop_before_tail=True).
+    pos_layer: h = EncoderEngine.forward(x, stop_before_tail=True, stop_before_pos=True), the INPUT of the last stride-2 layer
+    (pos_latent_tail_supported): that layer runs inside the call (vv_conv_pos_latent_tail_fwd).
     Returns (z float32 [B,L], z_act bf16, kl [B] or None, enc_out or None, h1 = the decoder's first-layer output)."""
     enc.ensure_packed()
     dec.ensure_packed()
@@ -626,6 +649,23 @@ def latent_tail(enc, dec, h, eps, variational, want_enc_out=False):
     K5 = enc.S ** 3 * enc.filters[-2]
     lin, n1 = dec.S ** 3 * dec.ch, dec.S ** 3 * dec.filters[0]
     ne = len(enc.filters) - 1
+    if pos_layer:
+        if tuple(h.shape[1:]) != (4, 4, 4, enc.filters[-3]):
+            raise L.VoxVaeError('latent_tail(pos_layer=True) takes the [B,4,4,4,%d] input of the last stride-2 layer, got %s' % (enc.filters[-3], tuple(h.shape)))
+        z = torch.empty(B, Lz, dtype=torch.float32, device=dev)
+        z_act = torch.empty(B, Lz, dtype=torch.bfloat16, device=dev)
+        kl = torch.empty(B, dtype=torch.float32, device=dev) if variational else None
+        enc_out = torch.empty(B, E, dtype=torch.float32, device=dev) if want_enc_out else None
+        h1 = torch.empty(B, dec.S, dec.S, dec.S, dec.filters[0], dtype=torch.bfloat16, device=dev)
+        c3, c4 = enc.filters[-3], enc.filters[-2]
+        ws = enc.ws.get(L.load().vv_conv_pos_latent_tail_workspace_bytes(B, c3, c4, E))
+        pe, pd = enc.packed, dec.packed
+        i4 = ne - 1
+        enc._call('E%dLT' % ne, 'vv_conv_pos_latent_tail_fwd', L.ptr(h), L.ptr(pe['ws%d' % i4]), L.ptr(pe['scale%d' % i4]), L.ptr(pe['shift%d' % i4]),
+                  c3, c4, L.ptr(pe['w%d' % ne]), L.ptr(pe.get('scale%d' % ne)), L.ptr(eps), L.ptr(pd['wd']), L.ptr(pd['scaled']), L.ptr(pd['shiftd']),
+                  L.ptr(pd['w0']), L.ptr(pd['scale0']), L.ptr(pd['shift0']), L.ptr(enc_out), L.ptr(z), L.ptr(z_act), L.ptr(kl), L.ptr(h1), B, E, Lz,
+                  lin, n1, int(variational), dec.act, L.VV_BF16, L.ptr(ws), ws.numel(), _stream())
+        return z, z_act, kl, enc_out, h1
     z = torch.empty(B, Lz, dtype=torch.float32, device=dev)
     z_act = torch.empty(B, Lz, dtype=torch.bfloat16, device=dev)
     kl = torch.empty(B, dtype=torch.float32, device=dev) if variational else None

@@ -77,6 +77,9 @@ SIGNATURES = {
     'vv_latent_tail_supported': (_i, [_i, _i, _i, _i, _i, _i, _i]),
     'vv_latent_tail_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'vv_latent_tail_fwd': (_i, [_vp] * 15 + [_i] * 9 + [_vp, _sz, _vp]),
+    'vv_conv_pos_latent_tail_supported': (_i, [_i] * 8),
+    'vv_conv_pos_latent_tail_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'vv_conv_pos_latent_tail_fwd': (_i, [_vp] * 4 + [_i, _i] + [_vp] * 14 + [_i] * 8 + [_vp, _sz, _vp]),
     'vv_reparam_kl_fwd': (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     'vv_convT3d_final_bce_workspace_bytes': (_sz, [_i, _i]),
     'vv_convT3d_final_bce_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _vp]),

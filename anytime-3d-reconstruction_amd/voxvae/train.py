@@ -328,8 +328,12 @@ class Trainer:
     def _wgrad_conv(self, src, g, out, batch, side, cin, cout):
         o = side // 2
         ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(batch * o ** 3, 64 * cin, cout))
+        tm = getattr(self, 'timer', None)            # bench.py's roofline leg: HIP events around the launch, on its stream
+        tok = tm.begin('wgrad:%d:%d:%d' % (side, cin, cout)) if tm is not None else None
         L.call('vv_wgrad_conv_k4s2', L.ptr(src), L.ptr(g), L.ptr(out), batch, side, cin, cout, self._dt(src), self._dt(g), L.ptr(ws),
                ws.numel(), _st())
+        if tm is not None:
+            tm.end(tok)
 
     def _conv(self, x, w_keras, B, side, cin, cout, packed=None):
         """Conv3D k4 s2 of x [B,side^3,cin] with a Keras kernel array read as [4,4,4,cin,cout]: the forward layers (packed =

@@ -265,14 +265,39 @@ def time_steps(fn, steps, warmup):
 
 
 # ------------------------------------------------------------------------------------------------ training mode
-def bench_train(a, model, x, eps, world, rank, dev, dist):
+def train_cpu_baseline(cfg, ep, dp, xh, epsh, n=8, min_seconds=10.0, max_steps=6):
+    """The training step on the host cores: oracle/torch_oracle.fit_step (torch-CPU autograd + Keras Adam) in the reference's own
+    float32, on a bounded sample of the same workload (n samples of the batch, BatchNorm over those n)."""
+    from oracle import torch_oracle as to
+    n = min(n, xh.shape[0])
+    xs, es = xh[:n], epsh[:n]
+    to.fit_step(cfg, ep, dp, xs, xs, es, dtype=torch.float32)          # thread pool / oneDNN primitive caches
+    t0, k = time.perf_counter(), 0
+    while k < max_steps and (k < 1 or time.perf_counter() - t0 < min_seconds):
+        to.fit_step(cfg, ep, dp, xs, xs, es, dtype=torch.float32)
+        k += 1
+    el = time.perf_counter() - t0
+    return {'value': n * k / el, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d fit steps (forward with batch statistics + autograd backward + Adam) on %d samples of the batch, torch-CPU float32 '
+                      '(oracle/torch_oracle.fit_step); %.1f s' % (k, n, el)}
+
+
+def bench_train(a, model, x, eps, world, rank, dev, dist, cfg=None, ep=None, dp=None, xh=None, epsh=None):
     """Training-step throughput (BASELINE.json configs[3]: batch sharded over the ranks, gradients summed by RCCL)."""
     from voxvae import train as T
+    from voxvae import engine as E
+    from voxvae import workload
     tr = T.Trainer(model._enc_eng, model._dec_eng, True, 1e-4, world_size=world, grad_wire=a.grad_wire)
     # Under a launcher the gradient buckets always go through RCCL, also with one rank (same code path as N > 1)
     tr.grads.always_reduce = dist is not None
+    # dominant kernel of the step: the weight gradient of the widest layer pair (E2 and D4 share one shape: 16^3 x 64 <-> 8^3 x 128,
+    # wgrad_phase_kernel<3> + the reduce of its slabs = one vv_wgrad_conv_k4s2 call, twice per step); HIP events on the launch stream
+    fe = model._enc_eng.filters
+    dom = 'wgrad:%d:%d:%d' % (a.voxel // 2, fe[0], fe[1])
+    tr.timer = E.LayerTimer(only=dom)
     for _ in range(a.warmup):
         tr.step(x, x, eps)
+    tr.timer.events.clear()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -301,6 +326,21 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
                    'all_reduce_ms_back_to_back': total, 'exposed_ms_after_backward': exposed,
                    'overlapped_fraction': (max(0.0, 1.0 - exposed / total) if total > 0 else None),
                    'launch_order': list(tr.grads.launch_order)}
+    roof = cpu = None
+    evs = tr.timer.events.get(dom, [])
+    tr.timer = None
+    if evs and cfg is not None:
+        lm = {n: v for n, v, _ in workload.layer_macs(cfg)}
+        kms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+        fl = 2.0 * lm['E2'] * a.batch                   # one multiply-add per (valid tap, ci, co, output voxel, sample): the forward layer's MACs
+        ach = fl / (kms * 1e-3) / 1e12
+        pk = PEAK['f32' if a.dtype == 'f32' else 'bf16'] / 1e12
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': pk, 'unit': 'TFLOP/s', 'frac': ach / pk, 'traffic': None,
+                'kernel': 'wgrad_phase_kernel<3> + wgrad_reduce_sliced_kernel = one vv_wgrad_conv_k4s2 call (weight gradient of E2 / D4, '
+                          '16^3 x %d <-> 8^3 x %d)' % (fe[0], fe[1]),
+                'launch_ms': kms, 'launches_timed': len(evs), 'algorithmic_flop_per_launch': fl}
+    if rank == 0 and world == 1 and a.cpu_samples > 0 and cfg is not None:
+        cpu = train_cpu_baseline(cfg, ep, dp, xh, epsh)
     if rank == 0:
         print(json.dumps({'metric': '32^3 voxel VAE training samples/sec (fit: fwd + bwd + Adam)', 'value': world * a.batch * a.steps / el,
                           'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * el / a.steps,
@@ -310,6 +350,7 @@ def bench_train(a, model, x, eps, world, rank, dev, dist):
                                      'parallelism': 'dp%d, bucketed RCCL all-reduce of gradients, per-rank BatchNorm' % world},
                           'rccl_world_size': nranks, 'process_group': dist.get_backend() if dist is not None else None,
                           'global_metrics': global_metrics(sums), 'gradient_all_reduce': overlap,
+                          'roofline': roof, 'cpu_baseline': cpu,
                           'final_loss_shape': float(metrics[0]), 'final_loss_kl': float(kl.mean())}))
     if dist is not None:
         dist.destroy_process_group()
@@ -419,7 +460,7 @@ def main():
         return model.eval_forward_device(x, x, eps)
 
     if a.mode == 'train':
-        return bench_train(a, model, x, eps, world, rank, dev, dist)
+        return bench_train(a, model, x, eps, world, rank, dev, dist, cfg, ep, dp, xh, epsh)
 
     # ---- per-layer breakdown (outside the timed region) -> dominant kernel
     lm = {n: v for n, v, _ in workload.layer_macs(cfg)}

@@ -203,6 +203,20 @@ int vv_latent_tail_fwd(const void *h, const void *w5, const float *e5_scale, con
                        void *z_act, float *kl, void *h1, int batch, int K5, int E, int L, int lin, int n1, int variational, int act,
                        int dtype, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The last stride-2 encoder layer (conv3DEnc at 4^3 -> 2^3, autoencoder3D.py:26-39 / :84-85) AND the latent tail above in three
+ * launches (posgemm.hip + latent_tail.hip): the convolution leaves only its float32 split-K partial sums, and the encoder-tail
+ * kernel sums them in share order, applies that layer's folded BN (scale4 / shift4, may be NULL) + act and rounds to bf16 while it
+ * builds its own operand -- the same values, in the same order, as vv_conv3d_k4s2_pos_fwd followed by vv_latent_tail_fwd, without the
+ * reduce launch and without the [B][2^3][cout4] activation in memory.  x4 [B][4^3][cin4] bf16, w4_skip = vv_pack_conv_k4_skip's
+ * image; K5 = 8 * cout4; the other arguments as vv_latent_tail_fwd.  cout4 % 256 == 0, E % 16 == 0, E <= 128. */
+int vv_conv_pos_latent_tail_supported(int cin4, int cout4, int E, int L, int lin, int n1, int variational, int dtype);
+size_t vv_conv_pos_latent_tail_workspace_bytes(int batch, int cin4, int cout4, int E);
+int vv_conv_pos_latent_tail_fwd(const void *x4, const void *w4_skip, const float *scale4, const float *shift4, int cin4, int cout4,
+                                const void *w5, const float *e5_scale, const float *eps, const void *wd, const float *scale_d,
+                                const float *shift_d, const void *w1, const float *scale_1, const float *shift_1, float *enc_out,
+                                float *z, void *z_act, float *kl, void *h1, int batch, int E, int L, int lin, int n1, int variational,
+                                int act, int dtype, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Latent ops */
 

@@ -14,10 +14,11 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS, BN_MOM = 1e-3, 0.99
+_DTYPE = [torch.float64]      # float64 = the oracle; bench.py's training cpu_baseline leg times the same graph in float32 (dtype= of fit_step)
 
 
 def _t(a, grad=False):
-    t = torch.tensor(np.asarray(a), dtype=torch.float64)
+    t = torch.tensor(np.asarray(a), dtype=_DTYPE[0])
     t.requires_grad_(grad)
     return t
 
@@ -77,7 +78,7 @@ def forward_train(config, P, x, y, eps, variational=True, drop_mask=None, drop_s
         z = mu + torch.sqrt(torch.exp(lv)) * eps
         kl = (0.5 * (0.0 - lv) + (torch.exp(lv) + mu ** 2) / 2.0 - 0.5).sum(-1).mean()
     else:
-        z, kl = e, torch.zeros((), dtype=torch.float64)
+        z, kl = e, torch.zeros((), dtype=_DTYPE[0])
     if drop_mask is not None:
         z = z * drop_mask * drop_scale
     if aux is not None:                      # the encoder output and the decoder input, for the builder-level model(x, training=True) tests
@@ -111,8 +112,15 @@ def trainable_names(P):
     return [k for k in P if not k.endswith(('moving_mean', 'moving_variance'))]
 
 
-def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variational=True, drop_mask=None, drop_scale=1.0):
-    """One reference training step.  Returns dict with losses, grads, updated params, updated moving stats, adam state."""
+def fit_step(config, enc_p, dec_p, x, y, eps, adam_state=None, lr=1e-4, variational=True, drop_mask=None, drop_scale=1.0, dtype=None):
+    """One reference training step.  Returns dict with losses, grads, updated params, updated moving stats, adam state.
+    dtype=torch.float32: the same graph in the reference's own precision (timing leg of bench.py --mode train; the tests use float64)."""
+    if dtype is not None:
+        _DTYPE.insert(0, dtype)
+        try:
+            return fit_step(config, enc_p, dec_p, x, y, eps, adam_state, lr, variational, drop_mask, drop_scale)
+        finally:
+            _DTYPE.pop(0)
     P = {}
     for k, v in enc_p.items():
         P['enc/' + k] = _t(v, grad=not k.endswith(('moving_mean', 'moving_variance')))

@@ -377,6 +377,75 @@ def test_latent_tail(L, B, K5, Lz, lin, n1, variational):
     _check(h1, ref, 'bf16', 'latent_tail')
 
 
+# the last stride-2 encoder layer + the latent tail as ONE call (round 4): the layer's split-K partial sums are summed by the tail's
+# first kernel.  Against the two calls it replaces (vv_conv3d_k4s2_pos_fwd -> vv_latent_tail_fwd: same share order, same bf16 rounding
+# of the layer output, so the encoder output differs only by the float32 summation order of the tail GEMM) and, for the layer
+# itself, against the float64 definition through the encoder output.
+@pytest.mark.parametrize('B,cin,cout,Lz,variational', [(256, 256, 512, 64, True), (37, 64, 256, 32, True), (300, 128, 512, 64, False),
+                                                       (5, 64, 256, 64, True)])
+def test_conv_pos_latent_tail_fused(L, B, cin, cout, Lz, variational):
+    rng = np.random.default_rng(B * 7 + cin)
+    E = 2 * Lz if variational else Lz
+    K5, lin, n1 = 8 * cout, 64, 4096
+    assert L.load().vv_conv_pos_latent_tail_supported(cin, cout, E, Lz, lin, n1, int(variational), L.VV_BF16)
+    x = _bf16_round(rng.standard_normal((B, 4, 4, 4, cin)).astype(np.float32))
+    w4 = _bf16_round((rng.standard_normal((4, 4, 4, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32))
+    sc4, sh4 = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(0, 0.3, cout).astype(np.float32)
+    w5 = _bf16_round((rng.standard_normal((E, K5)) / np.sqrt(K5)).astype(np.float32) * 3)
+    eps = rng.standard_normal((B, Lz)).astype(np.float32)
+    wd = _bf16_round((rng.standard_normal((lin, Lz)) / np.sqrt(Lz)).astype(np.float32))
+    w1 = _bf16_round((rng.standard_normal((n1, lin)) / np.sqrt(lin)).astype(np.float32))
+    scd, shd = rng.uniform(0.5, 1.5, lin).astype(np.float32), rng.normal(0, 0.3, lin).astype(np.float32)
+    sc1, sh1 = rng.uniform(0.5, 1.5, n1).astype(np.float32), rng.normal(0, 0.3, n1).astype(np.float32)
+    bt = torch.bfloat16
+    xd, w4d, sc4d, sh4d = _dev(x, bt), _dev(w4), _dev(sc4), _dev(sh4)
+    w5d, wdd, w1d = _dev(w5, bt), _dev(wd, bt), _dev(w1, bt)
+    epsd, scdd, shdd, sc1d, sh1d = _dev(eps), _dev(scd), _dev(shd), _dev(sc1), _dev(sh1)
+    wp = torch.empty(64 * cin * cout, dtype=bt, device=DEV)
+    L.call('vv_pack_conv_k4_skip', L.ptr(w4d), L.ptr(wp), cin, cout, _st())
+    lib = L.load()
+
+    def outs():
+        return (torch.full((B, E), float('nan'), dtype=torch.float32, device=DEV), torch.full((B, Lz), float('nan'), dtype=torch.float32, device=DEV),
+                torch.empty(B, Lz, dtype=bt, device=DEV), torch.full((B,), float('nan'), dtype=torch.float32, device=DEV),
+                torch.full((B, n1), float('nan'), dtype=bt, device=DEV))
+
+    # the two calls
+    ws = torch.empty(max(lib.vv_conv3d_k4s2_pos_workspace_bytes(B, cin, cout), 16), dtype=torch.uint8, device=DEV)
+    h4 = torch.full((B, 2, 2, 2, cout), float('nan'), dtype=bt, device=DEV)
+    L.call('vv_conv3d_k4s2_pos_fwd', L.ptr(xd), L.ptr(wp), L.ptr(sc4d), L.ptr(sh4d), L.ptr(h4), B, 4, cin, cout, 1, L.VV_BF16, L.ptr(ws), ws.numel(), _st())
+    e0, z0, zb0, kl0, h10 = outs()
+    ws2 = torch.empty(max(lib.vv_latent_tail_workspace_bytes(B, K5, E, n1), 16), dtype=torch.uint8, device=DEV)
+    L.call('vv_latent_tail_fwd', L.ptr(h4), L.ptr(w5d), None, L.ptr(epsd) if variational else None, L.ptr(wdd), L.ptr(scdd), L.ptr(shdd),
+           L.ptr(w1d), L.ptr(sc1d), L.ptr(sh1d), L.ptr(e0), L.ptr(z0), L.ptr(zb0), L.ptr(kl0) if variational else None, L.ptr(h10),
+           B, K5, E, Lz, lin, n1, int(variational), 1, L.VV_BF16, L.ptr(ws2), ws2.numel(), _st())
+    # the fused call
+    e1, z1, zb1, kl1, h11 = outs()
+    need = lib.vv_conv_pos_latent_tail_workspace_bytes(B, cin, cout, E)
+    assert need > 0
+    ws3 = torch.empty(need, dtype=torch.uint8, device=DEV)
+    L.call('vv_conv_pos_latent_tail_fwd', L.ptr(xd), L.ptr(wp), L.ptr(sc4d), L.ptr(sh4d), cin, cout, L.ptr(w5d), None,
+           L.ptr(epsd) if variational else None, L.ptr(wdd), L.ptr(scdd), L.ptr(shdd), L.ptr(w1d), L.ptr(sc1d), L.ptr(sh1d), L.ptr(e1), L.ptr(z1),
+           L.ptr(zb1), L.ptr(kl1) if variational else None, L.ptr(h11), B, E, Lz, lin, n1, int(variational), 1, L.VV_BF16, L.ptr(ws3), ws3.numel(), _st())
+    torch.cuda.synchronize()
+    en0, en1 = e0.cpu().numpy().astype(np.float64), e1.cpu().numpy().astype(np.float64)
+    tol = 2e-5 * max(1.0, np.abs(en0).max())
+    np.testing.assert_allclose(en1, en0, rtol=0, atol=tol)            # same operands, float32 summation order only
+    # the float64 definition of the tail on the bf16 layer output the unfused kernel stored
+    ref = h4.float().cpu().numpy().astype(np.float64).reshape(B, K5) @ w5.astype(np.float64).T
+    np.testing.assert_allclose(en1, ref, rtol=0, atol=tol)
+    np.testing.assert_allclose(z1.cpu().numpy(), z0.cpu().numpy(), rtol=2e-5, atol=tol)
+    if variational:
+        np.testing.assert_allclose(kl1.cpu().numpy(), kl0.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    assert torch.equal(zb1, z1.to(bt))
+    d = (h11.float() - h10.float()).abs().max().item()
+    assert d <= 0.05 * max(1.0, h10.float().abs().max().item()), d       # bf16 outputs of two dense layers on latents one float32 ulp apart
+    # too small a workspace is refused, nothing is launched
+    assert lib.vv_conv_pos_latent_tail_fwd(L.ptr(xd), L.ptr(wp), L.ptr(sc4d), L.ptr(sh4d), cin, cout, L.ptr(w5d), None, L.ptr(epsd), L.ptr(wdd),
+                                           L.ptr(scdd), L.ptr(shdd), L.ptr(w1d), L.ptr(sc1d), L.ptr(sh1d), L.ptr(e1), L.ptr(z1), L.ptr(zb1), L.ptr(kl1),
+                                           L.ptr(h11), B, E, Lz, lin, n1, int(variational), 1, L.VV_BF16, L.ptr(ws3), need - 16, _st()) == -5
+
+
 def test_reparam_kl(L):
     rng = np.random.default_rng(0)
     for B, Lz in ((5, 64), (3, 16), (2, 100)):
