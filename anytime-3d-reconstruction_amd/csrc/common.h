@@ -168,8 +168,14 @@ void vv_wgrad_phase_launch(const void *src, const void *g, float *slabs, int bat
 int vv_final_bce_sweep_fp8_launch(const void *x, const float *w_keras, const float *target, float *probs, float *logits, float *partials,
                                   int batch, int side, float gamma, float epsilon, hipStream_t st);
 
-// posgemm.hip (internal): the 4^3 -> 2^3 convolution written as float32 split-K slabs only; slab of (position p, share s, sample
-// tile mt) = ws + ((first[p] + s) * mtiles + mt) * rows_per_tile * cout floats, rows = samples of the tile, cout floats per row.
-struct VvPgSlabPlan { int npos, mtiles, nitems, rows_per_tile; unsigned char nsplit[8]; unsigned short first[8]; };
+// posgemm.hip (internal): the 4^3 -> 2^3 convolution written as float32 split-K slabs only, in the MFMA FRAGMENT order of the
+// producing workgroup (no transpose on the producer's side).  Piece of (position p, share s, sample tile mt, channel tile nt) =
+// ws + (((first[p] + s) * mtiles + mt) * ntn + nt) * 256 * 128 floats; inside a piece the f32x4 holding channels c .. c + 3 (c % 4 == 0,
+// local to the 128-channel tile) of local row r sits at index vv_pg_frag_index(r, c).
+struct VvPgSlabPlan { int npos, mtiles, nitems, rows_per_tile, ntn; unsigned char nsplit[8]; unsigned short first[8]; };
 size_t vv_pg_conv_slab_bytes(int batch, int cin, int cout);
 int vv_pg_conv_slabs(const void *x, const void *w, int batch, int cin, int cout, void *ws, size_t ws_bytes, hipStream_t st, VvPgSlabPlan *plan);
+// wave = (r >> 6) * 2 + (c >> 6); nt_ = (c >> 5) & 1; mt_ = (r >> 5) & 1; g = (c >> 3) & 3; lane = ((c >> 2) & 1) * 32 + (r & 31)
+__host__ __device__ inline int vv_pg_frag_index(int r, int c) {
+    return ((((((r >> 6) * 2 + (c >> 6)) * 2 + ((c >> 5) & 1)) * 2 + ((r >> 5) & 1)) * 4 + ((c >> 3) & 3)) * 64) + ((c >> 2) & 1) * 32 + (r & 31);
+}

@@ -302,7 +302,7 @@ struct LtE5xArgs {
     const float *scale4, *shift4;
     const void *w5;           // [E][K5] bf16, K5 = 8 * cout4
     float *slabs;             // [8 * nh][B][E]
-    int batch, cout4, E, nh, mtiles, rows_per_tile, act;
+    int batch, cout4, E, nh, mtiles, rows_per_tile, ntn, act;
     unsigned char nsplit[8];
     unsigned short first[8];
 };
@@ -335,17 +335,25 @@ __global__ __launch_bounds__(256) void lt_e5x_kernel(const LtE5xArgs a) {
                                       : make_uint4(0, 0, 0, 0);
         }
     }
-    // ---- the tile: thread = (row tid >> 4, channel quads (tid & 15) * 4 + 64 j, j = 0..3: the 16 lanes of a row read 256 contiguous
-    // bytes per load): shares summed in order, BN, activation, bf16
+    // ---- the tile: thread = (row tid & 15, channel quads (tid >> 4) + 16 j, j = 0..3).  The slabs are in the producer's fragment
+    // order (vv_pg_frag_index): 16 consecutive rows of one quad are 256 contiguous bytes.  Shares summed in order, BN, activation, bf16
     {
-        const int r = tid >> 4, cg = tid & 15;
+        const int r = tid & 15, qg = tid >> 4;
         const int b = b0 + r;
         const bool live = b < a.batch;
         const int mt = b0 / a.rows_per_tile, rl = b - mt * a.rows_per_tile;
-        const int c0 = chh * 256 + cg * 4;
         const int ns = a.nsplit[p];
-        const float *src = a.pslabs + (((size_t)a.first[p] * a.mtiles + mt) * a.rows_per_tile + (live ? rl : 0)) * a.cout4 + c0;
-        const size_t sstride = (size_t)a.mtiles * a.rows_per_tile * a.cout4;
+        const size_t piece = (size_t)a.rows_per_tile * 128 / 4;                 // f32x4 per [256][128] piece
+        const size_t sstride = (size_t)a.mtiles * a.ntn * piece;               // one share further
+        const f32x4 *src[4];
+        int cch[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = chh * 256 + (qg + 16 * j) * 4;                        // channel of the layer
+            cch[j] = c;
+            src[j] = reinterpret_cast<const f32x4 *>(a.pslabs) + (((size_t)a.first[p] * a.mtiles + mt) * a.ntn + (c >> 7)) * piece +
+                     vv_pg_frag_index(live ? rl : 0, c & 127);
+        }
         f32x4 s[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         for (int s0 = 0; s0 < ns; s0 += 4) {             // 16 independent 16-byte loads in flight per trip
             f32x4 v[4][4];
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(256) void lt_e5x_kernel(const LtE5xArgs a) {
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    v[k][j] = (live && s0 + k < ns) ? *reinterpret_cast<const f32x4 *>(src + (size_t)(s0 + k) * sstride + j * 64) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[k][j] = (live && s0 + k < ns) ? src[j][(size_t)(s0 + k) * sstride] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -362,12 +370,12 @@ __global__ __launch_bounds__(256) void lt_e5x_kernel(const LtE5xArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (a.scale4) sc = *reinterpret_cast<const f32x4 *>(a.scale4 + c0 + j * 64);
-            if (a.shift4) sh = *reinterpret_cast<const f32x4 *>(a.shift4 + c0 + j * 64);
+            if (a.scale4) sc = *reinterpret_cast<const f32x4 *>(a.scale4 + cch[j]);
+            if (a.shift4) sh = *reinterpret_cast<const f32x4 *>(a.shift4 + cch[j]);
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(live ? lt_act<ACT>(s[j][e] * sc[e] + sh[e]) : 0.f);
-            *reinterpret_cast<bf16x4 *>(xs + r * LTX_PITCH + (j * 64 + cg * 4) * 2) = o;
+            *reinterpret_cast<bf16x4 *>(xs + r * LTX_PITCH + (cch[j] - chh * 256) * 2) = o;
         }
     }
     __syncthreads();
@@ -508,7 +516,7 @@ VV_EXPORT int vv_conv_pos_latent_tail_fwd(const void *x4, const void *w4_skip, c
     a.pslabs = reinterpret_cast<const float *>(workspace);
     a.scale4 = scale4; a.shift4 = shift4; a.w5 = w5;
     a.slabs = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + sl);
-    a.batch = batch; a.cout4 = cout4; a.E = E; a.nh = nh; a.mtiles = plan.mtiles; a.rows_per_tile = plan.rows_per_tile; a.act = act;
+    a.batch = batch; a.cout4 = cout4; a.E = E; a.nh = nh; a.mtiles = plan.mtiles; a.rows_per_tile = plan.rows_per_tile; a.ntn = plan.ntn; a.act = act;
     for (int p = 0; p < 8; ++p) { a.nsplit[p] = plan.nsplit[p]; a.first[p] = plan.first[p]; }
     const dim3 grid(((batch + 15) / 16) * nslice);
     switch (act) {

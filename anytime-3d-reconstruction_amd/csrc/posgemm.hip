@@ -241,7 +241,23 @@ __global__ __launch_bounds__(512, 1) void pg_kernel(const PgArgs a) {
 
     // ---- epilogue.  lane = sample row fr of row tile mt_, registers walk channels (q & 3) + 8 (q >> 2) + 4 fh of channel
     // tile nt_.  One share: folded BN + activation, bf16, the layer's output.  Several: float32 slab.
-    const bool final_out = nshare == 1 && !a.force_slabs;
+    if (a.force_slabs) {
+        // Slabs for a consumer that sums them itself (latent_tail.hip, lt_e5x_kernel): the accumulators go out in FRAGMENT order, one
+        // 1 KiB store per wave and register quad -- f32x4 index ((((wave * 2 + nt_) * 2 + mt_) * 4 + g) * 64 + lane) of the
+        // workgroup's [256 rows][128 channels] piece, pieces laid out [slot][sample tile][channel tile] -- no LDS transpose, no barrier.
+        // Rows past the batch carry zeros (their activation rows were zero-filled).
+        f32x4 *piece = reinterpret_cast<f32x4 *>(a.slabs) + (((size_t)slot * a.mtiles + mt) * a.ntn + nt) * (PG_BM * PG_BN / 4);
+#pragma unroll
+        for (int nt_ = 0; nt_ < 2; ++nt_)
+#pragma unroll
+            for (int mt_ = 0; mt_ < 2; ++mt_)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    piece[(((wave * 2 + nt_) * 2 + mt_) * 4 + g) * 64 + lane] =
+                        f32x4{acc[nt_][mt_][4 * g], acc[nt_][mt_][4 * g + 1], acc[nt_][mt_][4 * g + 2], acc[nt_][mt_][4 * g + 3]};
+        return;
+    }
+    const bool final_out = nshare == 1;
     const int m_rows = a.batch - m0 < PG_BM ? a.batch - m0 : PG_BM;
     auto fill = [&](auto act_c, auto fin_c) {
         constexpr int ACT = decltype(act_c)::value;
@@ -446,7 +462,9 @@ bool pg_shape_ok(int cin, int cout) {
 // its own MFMA operand.  One launch; the whole batch must fit 32-bit buffer offsets.
 size_t vv_pg_conv_slab_bytes(int batch, int cin, int cout) {
     if (batch <= 0 || !pg_shape_ok(cin, cout) || (size_t)batch * 64 * cin * 2 > 0x7FFFFFFFull) return 0;
-    return pg_ws_bytes<0>(batch, cin, cout);
+    PgArgs a;
+    pg_plan<0>(a, batch, cin, cout);
+    return (size_t)a.nitems * a.mtiles * a.ntn * PG_BM * PG_BN * sizeof(float);      // whole [256][128] pieces in fragment order
 }
 
 int vv_pg_conv_slabs(const void *x, const void *w, int batch, int cin, int cout, void *ws, size_t ws_bytes, hipStream_t st, VvPgSlabPlan *plan) {
@@ -467,7 +485,7 @@ int vv_pg_conv_slabs(const void *x, const void *w, int batch, int cin, int cout,
     a.x_bytes = (unsigned)((size_t)batch * 64 * cin * 2);
     a.w_bytes = (unsigned)((size_t)64 * cin * cout * 2);
     VV_LAUNCH(pg_kernel<0>, dim3(a.nitems * a.ntn * a.mtiles), dim3(512), PG_LDS, st, a);
-    plan->npos = a.npos; plan->mtiles = a.mtiles; plan->nitems = a.nitems; plan->rows_per_tile = PG_BM;
+    plan->npos = a.npos; plan->mtiles = a.mtiles; plan->nitems = a.nitems; plan->rows_per_tile = PG_BM; plan->ntn = a.ntn;
     for (int p = 0; p < 8; ++p) { plan->nsplit[p] = a.nsplit[p]; plan->first[p] = a.first[p]; }
     return vv_launch_status();
 }

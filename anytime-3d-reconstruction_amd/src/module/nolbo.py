@@ -189,7 +189,10 @@ class _ModelnetBase(object):
         if getattr(self, '_enc_eng', None) is None or input_images.ndim != 5:
             return None                                  # the image -> 3D model: its inputs are images / head outputs, not voxel grids
         B = int(input_images.shape[0])
-        nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2'))
+        # Two chunks pay when the download is the long pole (float32 probabilities: 33.6 MB at the PCIe rate = 0.60 ms beside 0.49 ms of
+        # kernels); with the uint8 occupancy return (0.16 ms) one whole-batch pass is faster than two half-batch ones, whose
+        # one-workgroup-per-sample kernels fill half the chip each (profiles/r04_host_chunks.json: 0.94 against 1.05 ms per call)
+        nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2' if _H.prediction_host_dtype() == 'float32' else '1'))
 
         def usable(a):      # a float32 C-contiguous array, or a bit-packed host batch (voxvae/hostio.py: 1 bit per voxel over PCIe)
             return isinstance(a, _H.PackedVoxels) or (a.dtype == np.float32 and a.flags['C_CONTIGUOUS'])
