@@ -884,7 +884,8 @@ inline int bn_sweep_blocks(long R, int C, int V) {
     const int cvn = C / V;
     const int rows_par = 256 / cvn > 0 ? 256 / cvn : 1;
     long nb = (R + 2L * rows_par - 1) / (2L * rows_par);
-    return (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+    static const long cap = vv_hook("VV_BN_SWEEP") ? atol(vv_hook("VV_BN_SWEEP")) : 4096;
+    return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }
 
 inline int bn_blocks(long R, int C, int V = 4) {
@@ -894,7 +895,8 @@ inline int bn_blocks(long R, int C, int V = 4) {
     if (per < 16) per = 16;
     if (per > 256) per = 256;
     long nb = (R + per - 1) / per;
-    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+    static const long cap = vv_hook("VV_BN_NB") ? atol(vv_hook("VV_BN_NB")) : 1024;
+    return (int)(nb > cap ? cap : (nb < 1 ? 1 : nb));
 }
 
 }  // namespace

@@ -1,0 +1,69 @@
+"""Current-state table of DESIGN.md section 0 from the committed summaries of one round:
+   python profiles/state_table.py r04  ->  markdown on stdout
+layer -> kernel -> rocprofv3 average us (one batch at a time) -> achieved vs its roofline -> counter traffic vs algorithmic bytes ->
+MFMA busy / wave cycles parked -> what limits it.  Every number is recomputable from profiles/<round>_*."""
+import csv, json, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'anytime-3d-reconstruction_amd'))
+from voxvae import workload, synthetic as syn
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+B = 256
+cfg = syn.make_config(32, 64, True)
+macs = {n: v for n, v, _ in workload.layer_macs(cfg)}
+stats = {r['Name']: float(r['AverageNs']) / 1e3 for r in csv.DictReader(open(os.path.join(HERE, rnd + '_bf16_b256_kernel_stats.csv')))}
+ctr = {}
+for r in csv.DictReader(open(os.path.join(HERE, rnd + '_bf16_b256_counters.csv'))):
+    ctr.setdefault(r['Kernel_Name'], r)
+traffic = json.load(open(os.path.join(HERE, rnd + '_pmc_traffic.json')))['layers']
+
+def find(d, sub):
+    ks = [k for k in d if sub in k]
+    if len(ks) != 1:
+        raise SystemExit('%r matches %d kernels' % (sub, len(ks)))
+    return d[ks[0]]
+
+MB = 1e6
+act = lambda side, ch: B * side ** 3 * ch * 2            # bf16 activation bytes
+# layer, kernel substrings, bound, algorithmic bytes (input + output + weights read once), limiter
+rows = [
+    ('E1', ['first_conv_chain_kernel'], 'hbm', B * 32 ** 3 * 4 + act(16, 64), 'HBM: reads the float32 grid, writes the largest encoder activation'),
+    ('E2', ['conv_direct16_kernel'], 'mfma', act(16, 64) + act(8, 128) + 64 * 64 * 128 * 2, 'matrix pipe at the clock the chip holds under load; one 8-wave workgroup per CU in lockstep (barrier per tap chunk, epilogue with the pipe idle)'),
+    ('E3', ['sd_kernel<0>'], 'mfma', act(8, 128) + act(4, 256) + 64 * 128 * 256 * 2, 'its own MFMA + fragment-read stream (81 % of the kernel, r03 ablations); 23 % of the dense taps skipped'),
+    ('E4', ['pg_kernel<0>'], 'mfma', act(4, 256) + 64 * 256 * 512 * 2, 'split-K: 29 MB of float32 partial sums written here and read back by the tail; K loop is 10 of the 26 us'),
+    ('E4 sum + E5', ['lt_e5x_kernel'], 'latency', 8 * 512 * 128 * 2 + B * 128 * 4 * 16, 'one memory round trip over the 29 MB of partial sums'),
+    ('a3-a7 + D0 + D1', ['lt_mid_kernel'], 'latency', 0, 'dependent round trips: 16 slabs summed, two K = 64 dense layers'),
+    ('D2', ['pg_kernel<1>', 'pg_reduce_kernel<1'], 'mfma', act(2, 512) + act(4, 256) + 64 * 512 * 256 * 2, 'split-K slabs + the reduce launch (r03 ablations: two thirds of the layer)'),
+    ('D3', ['sd_kernel<1>'], 'mfma', act(4, 256) + act(8, 128) + 64 * 256 * 128 * 2, 'as E3 (91 % of the kernel is its MFMA + fragment-read stream); 11 us of prologue + epilogue'),
+    ('D4', ['ctw16_kernel'], 'mfma', act(8, 128) + act(16, 64) + 64 * 128 * 64 * 2, 'as E2: 207 k cycles per workgroup against 131 k of MFMA issue (eight parity epilogues 35 k, prologue 11 k, barriers); the four-wave tile was slower (r04_c4_ablations.json)'),
+    ('D5 + a10 + a11', ['final_bce_sweepw_kernel'], 'hbm', act(16, 64) + 2 * B * 32 ** 3 * 4, 'HBM (memory floor 31-35 us) + three transcendentals per voxel'),
+    ('a11 batch means', ['final_reduce_metrics_kernel'], 'latency', 0, 'launch latency'),
+]
+lname = {'E2': 'E2', 'E3': 'E3', 'E4': 'E4', 'D2': 'D2', 'D3': 'D3', 'D4': 'D4'}
+tkey = {'E1': 'E1', 'E2': 'E2', 'E3': 'E3', 'E4': 'E4', 'E4 sum + E5': 'E4sum_E5', 'D2': 'D2', 'D3': 'D3', 'D4': 'D4', 'D5 + a10 + a11': 'D5'}
+print('| layer (SURVEY 8a) | kernel(s) | us / launch (rocprofv3 average) | achieved | of roofline | counter traffic MB (algorithmic MB, ratio) | MFMA busy % | parked % (wait_any) | what limits it |')
+print('|---|---|---|---|---|---|---|---|---|')
+total = 0.0
+for layer, subs, bound, abytes, why in rows:
+    us = sum(find(stats, s) for s in subs)
+    total += us
+    c = find(ctr, subs[0])
+    if bound == 'mfma':
+        fl = 2.0 * macs[lname[layer]] * B
+        ach, frac = '%.0f TFLOP/s' % (fl / us / 1e6), '%.3f of 2.5 PFLOP/s' % (fl / us / 1e6 / 2500)
+    elif bound == 'hbm':
+        ach, frac = '%.2f TB/s' % (abytes / us / 1e6), '%.2f of 8 TB/s (%.2f of the 6.29 TB/s copy rate)' % (abytes / us / 1e6 / 8, abytes / us / 1e6 / 6.29)
+    else:
+        ach, frac = '-', 'latency'
+    tr = traffic.get(tkey.get(layer, ''), None)
+    if tr and abytes:
+        t = '%.1f (%.1f, %.2fx)' % (tr['hbm_bytes_per_launch'] / MB, abytes / MB, tr['hbm_bytes_per_launch'] / abytes)
+    elif tr:
+        t = '%.1f' % (tr['hbm_bytes_per_launch'] / MB)
+    else:
+        t = '-'
+    print('| %s | `%s` | %s | %s | %s | %s | %.1f | %.1f | %s |' % (layer, '` + `'.join(subs), ' + '.join('%.1f' % find(stats, s) for s in subs), ach, frac, t,
+                                                                  float(c['mfma_busy_pct']), float(c['wait_any_pct']), why))
+fl_rec, _ = workload.flops_per_reconstruction(cfg)
+print('| **whole path** | 12 launches | **%.1f** (sum of the averages, one batch at a time) | %.0f TFLOP/s | %.3f of 2.5 PFLOP/s | | | | three batches in flight on three streams overlap this to the `ms_per_step` of the bench line |'
+      % (total, fl_rec * B / total / 1e6, fl_rec * B / total / 1e6 / 2500))
