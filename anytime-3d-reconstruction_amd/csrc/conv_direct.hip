@@ -464,6 +464,231 @@ __global__ __launch_bounds__(512, 1) void conv_direct16_kernel(const __bf16 *__r
 }
 
 
+// ---- round 4: the same layer as TWO INDEPENDENT workgroups per CU (`conv_direct16h_kernel`).  conv_direct16_kernel is one 8-wave
+// workgroup per CU: both waves of a SIMD belong to it, reach every per-tap barrier together and leave the matrix pipe idle together
+// (50 % MFMA busy, 31 % of the wave cycles parked).  Here a workgroup is 4 waves (one per SIMD) on 256 outputs x 64 channels -- the wave
+// tile, the fragment layouts, the slot keys and the per-accumulator summation order are conv_direct16_kernel's -- with ONE phase-tile
+// buffer (52 KB) and 8 KB weight stages: 76 KB, so two workgroups share a CU and the second wave of every SIMD belongs to a workgroup
+// with its own barriers.  What a single buffer costs -- the next phase's tile can only be fetched once every wave has read the last
+// tap of this one, so the workgroup idles for one LDS-DMA round trip per phase -- is time the OTHER workgroup's waves have the SIMDs to
+// themselves; the workgroups of a CU are put half a phase apart at the start (hardware wave slot parity: timing only, any placement is
+// correct).  Every A tile is staged twice (once per channel half): 2 x 212 MB of L2 -> LDS traffic per launch instead of 1 x.
+constexpr int CDH_COUT = 64;
+constexpr int CDH_WST = CDH_COUT * 128;            // 8 KB weight stage
+constexpr int CDH_RING = CD_TILE;
+constexpr int CDH_DUMMY = CDH_RING + CD_NST * CDH_WST;
+constexpr int CDH_LDS = CDH_DUMMY + 1024;          // 77,824 B
+constexpr int CDH_SP = CDH_COUT * 2 + 16;          // epilogue row pitch (bf16; the fp8 form uses the same pitch)
+
+__global__ __launch_bounds__(256, 2) void conv_direct16h_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                void *__restrict__ y, int dout_log2, unsigned x_bytes, unsigned w_bytes,
+                                                                int act, int out_fp8, int stagger, int abl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = wm: output plane od0 + wave
+    const int wm = wave;
+    const int lo = dout_log2, no = 1 << lo, li = lo + 1, n = 1 << li;
+
+    // XCD-aware order: the two channel halves of a box, then the boxes of a sample, run on one XCD (they read the same tiles)
+    const int nwg = gridDim.x;
+    int blk = (nwg & 7) == 0 ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nh = blk & 1; blk >>= 1;
+    const int bxw = no >> 3, bxh = no >> 3, bxd = no >> 2;
+    const int bw = blk % bxw; blk /= bxw;
+    const int bh = blk % bxh; blk /= bxh;
+    const int bd = blk % bxd; const int b = blk / bxd;
+    const int od0 = bd * 4, oh0 = bh * 8, ow0 = bw * 8;
+
+    const u32x4 rsx = vv_make_rsrc(x, x_bytes), rsw = vv_make_rsrc(w, w_bytes);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // ---- producers
+    auto issue_x = [&](int q, int slot) {            // slot = 0..12: piece slot*4 + wave of phase q into THE tile
+        const int piece = slot * 4 + wave;
+        const int rl = piece * 8 + (lane >> 3);
+        const int zd = rl / 81, rem = rl - zd * 81, jh = rem / 9, jw = rem - jh * 9;
+        const int g = (lane & 7) ^ ((2 * jw) & 7);
+        const int id = 2 * (od0 + zd) + ((q >> 2) & 1) - 1, ih = 2 * (oh0 + jh) + ((q >> 1) & 1) - 1, iw = 2 * (ow0 + jw) + (q & 1) - 1;
+        const bool ok = rl < 405 && (unsigned)id < (unsigned)n && (unsigned)ih < (unsigned)n && (unsigned)iw < (unsigned)n;
+        const unsigned vo = ok ? (unsigned)((((((b << li) + id) << li) + ih) << li) + iw) * CD_RB + g * 16 : 0xFFFFFFF0u;
+        const unsigned dst = piece < CD_PIECES ? lds0 + piece * 1024 : lds0 + CDH_DUMMY;
+        vv_dma16(rsx, vo, dst);
+    };
+    auto issue_w = [&](int c) {                      // chunk c = q*8 + a into ring[c % 3]: rows 16*wave .. 16*wave+15 of this half
+        const int q = c >> 3, a = c & 7;
+        const int td = 2 * ((a >> 2) & 1) + ((q >> 2) & 1), th = 2 * ((a >> 1) & 1) + ((q >> 1) & 1), tw = 2 * (a & 1) + (q & 1);
+        const int t = (td * 4 + th) * 4 + tw;
+        const unsigned st = lds0 + CDH_RING + (c % CD_NST) * CDH_WST;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            const unsigned vo = c < 64 ? (unsigned)(nh * CDH_COUT + row) * (64 * CD_RB) + t * CD_RB + g * 16 : 0xFFFFFFF0u;
+            vv_dma16(rsw, vo, st + (wave * 2 + i) * 1024);
+        }
+    };
+
+    // ---- stagger: the workgroup in the odd wave slots of its SIMDs starts about half a phase later (timing only)
+    {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid & 1u) && stagger) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);      // 512 cycles per step
+        }
+    }
+    // ---- prologue: phase 0 tile, weight chunks 0..2
+#pragma unroll 1
+    for (int s = 0; s < 13; ++s) issue_x(0, s);
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- consumer addressing: conv_direct16_kernel's, channel tile base 0 (the workgroup's half starts at stage row 0)
+    const int r = lane & 15, kq = lane >> 4;
+    const int rl0 = wm * 81 + (r >> 3) * 9 + (r & 7);
+    unsigned xo[2][2], wo[2];
+#pragma unroll
+    for (int aw = 0; aw < 2; ++aw)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xo[aw][ks] = lds0 + rl0 * CD_RB + (((ks * 4 + kq) ^ ((2 * ((r & 7) + aw)) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wo[ks] = lds0 + CDH_RING + r * 128 + (((ks * 4 + kq) ^ ((r >> 1) & 7)) << 4);
+
+    f32x4 acc[4][4];                               // [cot][ct]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 P[8], Q[8];
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+        if (q > 0) {
+            // the refill of THE tile was issued behind the last barrier of phase q - 1 (tap 7 below); it has landed:
+            wait_vm<0>();                           // (also drains the weight pieces issued before them: in-order counter)
+            __syncthreads();
+        }
+        CD16_LD(P, xo[0][0], 0, wo[0] + ((q * 8) % CD_NST) * CDH_WST);      // chunk 8 q, k-step 0
+        auto tap = [&](auto a_c) {
+            constexpr int A = decltype(a_c)::value;
+            constexpr int AW = A & 1, TO = (((A >> 2) & 1) * 81 + ((A >> 1) & 1) * 9 + AW) * CD_RB;
+            constexpr int AN = (A + 1) & 7, AWN = AN & 1, TON = (((AN >> 2) & 1) * 81 + ((AN >> 1) & 1) * 9 + AWN) * CD_RB;
+            const int c = q * 8 + A;
+            const unsigned wsel = (c % CD_NST) * CDH_WST, wnext = ((c + 1) % CD_NST) * CDH_WST;
+            const unsigned xq = xo[AW][1], wq = wo[1] + wsel;
+            CD16_WAIT(P, 0);
+            CD16_SB;
+            CD16_MF(P, 0, 0); CD16_MF(P, 0, 1); CD16_SB; CD16_RD(Q[0], xq, TO); CD16_RD(Q[4], wq, 0); CD16_SB;
+            CD16_MF(P, 0, 2); CD16_MF(P, 0, 3); CD16_SB; CD16_RD(Q[1], xq, TO + 2304); CD16_RD(Q[5], wq, 2048); CD16_SB;
+            CD16_MF(P, 1, 0); CD16_MF(P, 1, 1); CD16_SB; CD16_RD(Q[2], xq, TO + 4608); CD16_RD(Q[6], wq, 4096); CD16_SB;
+            CD16_MF(P, 1, 2); CD16_MF(P, 1, 3); CD16_SB; CD16_RD(Q[3], xq, TO + 6912); CD16_RD(Q[7], wq, 6144); CD16_SB;
+            CD16_MF(P, 2, 0); CD16_MF(P, 2, 1); CD16_MF(P, 2, 2); CD16_MF(P, 2, 3);
+            CD16_MF(P, 3, 0); CD16_MF(P, 3, 1); CD16_MF(P, 3, 2); CD16_MF(P, 3, 3);
+            CD16_SB;
+            CD16_WAIT(Q, 0);                       // every LDS read of chunk c has returned: its stage may be refilled
+            // chunk c+1's weights have landed: the only pieces issued after w(c+1) are the two of w(c+2)
+            wait_vm<2>();
+            __syncthreads();
+            CD16_SB;
+            CD16_MF(Q, 0, 0); CD16_MF(Q, 0, 1);
+            CD16_MF(Q, 0, 2); CD16_MF(Q, 0, 3);
+            issue_w(c + 3);
+            CD16_SB;
+            if (A < 7) {
+                const unsigned xp = xo[AWN][0], wp = wo[0] + wnext;
+                CD16_MF(Q, 1, 0); CD16_MF(Q, 1, 1); CD16_SB; CD16_RD(P[0], xp, TON); CD16_RD(P[4], wp, 0); CD16_SB;
+                CD16_MF(Q, 1, 2); CD16_MF(Q, 1, 3); CD16_SB; CD16_RD(P[1], xp, TON + 2304); CD16_RD(P[5], wp, 2048); CD16_SB;
+                CD16_MF(Q, 2, 0); CD16_MF(Q, 2, 1); CD16_SB; CD16_RD(P[2], xp, TON + 4608); CD16_RD(P[6], wp, 4096); CD16_SB;
+                CD16_MF(Q, 2, 2); CD16_MF(Q, 2, 3); CD16_SB; CD16_RD(P[3], xp, TON + 6912); CD16_RD(P[7], wp, 6144); CD16_SB;
+            } else {
+                // Every wave has passed this tap's barrier with all its reads of the tile returned: the tile is free, and the refill
+                // for phase q + 1 goes out here, between the last MFMAs of the phase.  The next chunk's first fragments are read
+                // after it has landed (top of the phase loop).
+                const bool more = q < 7 && !(abl & 1);
+                CD16_MF(Q, 1, 0); CD16_MF(Q, 1, 1); CD16_SB;
+                if (more) { issue_x(q + 1, 0); issue_x(q + 1, 1); issue_x(q + 1, 2); }
+                CD16_SB; CD16_MF(Q, 1, 2); CD16_MF(Q, 1, 3); CD16_SB;
+                if (more) { issue_x(q + 1, 3); issue_x(q + 1, 4); issue_x(q + 1, 5); }
+                CD16_SB; CD16_MF(Q, 2, 0); CD16_MF(Q, 2, 1); CD16_SB;
+                if (more) { issue_x(q + 1, 6); issue_x(q + 1, 7); issue_x(q + 1, 8); }
+                CD16_SB; CD16_MF(Q, 2, 2); CD16_MF(Q, 2, 3); CD16_SB;
+                if (more) { issue_x(q + 1, 9); issue_x(q + 1, 10); issue_x(q + 1, 11); issue_x(q + 1, 12); }
+                CD16_SB;
+            }
+            CD16_MF(Q, 3, 0); CD16_MF(Q, 3, 1); CD16_MF(Q, 3, 2); CD16_MF(Q, 3, 3);
+            CD16_SB;
+        };
+        tap(std::integral_constant<int, 0>{});
+        tap(std::integral_constant<int, 1>{});
+        tap(std::integral_constant<int, 2>{});
+        tap(std::integral_constant<int, 3>{});
+        tap(std::integral_constant<int, 4>{});
+        tap(std::integral_constant<int, 5>{});
+        tap(std::integral_constant<int, 6>{});
+        tap(std::integral_constant<int, 7>{});
+    }
+    wait_vm<0>();                                   // trailing zero-fill pieces still target LDS
+    __syncthreads();
+
+    // ---- epilogue: lane = output (wm, ct, r); registers walk channels nh*64 + 16 cot + 4 kq ..
+    char *stage = smem;
+    f32x4 scv[4], shv[4];
+#pragma unroll
+    for (int cot = 0; cot < 4; ++cot) { scv[cot] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[cot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (scale) {
+#pragma unroll
+        for (int cot = 0; cot < 4; ++cot) scv[cot] = *reinterpret_cast<const f32x4 *>(scale + nh * CDH_COUT + cot * 16 + 4 * kq);
+    }
+    if (shift) {
+#pragma unroll
+        for (int cot = 0; cot < 4; ++cot) shv[cot] = *reinterpret_cast<const f32x4 *>(shift + nh * CDH_COUT + cot * 16 + 4 * kq);
+    }
+    auto fill = [&](auto act_c, auto fp8_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool FP8 = decltype(fp8_c)::value;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int cot = 0; cot < 4; ++cot) {
+                const int c = cot * 16 + 4 * kq;
+                const f32x4 v = vv_bn_act4<ACT>(acc[cot][ct], scv[cot], shv[cot]);
+                char *dst = stage + (wm * 64 + ct * 16 + r) * CDH_SP;
+                if (FP8) {
+                    *reinterpret_cast<unsigned *>(dst + c) = vv_pack_fp8x4(v);
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = static_cast<__bf16>(v[e]);
+                    *reinterpret_cast<bf16x4 *>(dst + c * 2) = o;
+                }
+            }
+    };
+    auto with_out = [&](auto act_c) {
+        if (out_fp8) fill(act_c, std::true_type{});
+        else fill(act_c, std::false_type{});
+    };
+    switch (act) {
+        case VV_ACT_ELU: with_out(std::integral_constant<int, VV_ACT_ELU>{}); break;
+        case VV_ACT_RELU: with_out(std::integral_constant<int, VV_ACT_RELU>{}); break;
+        case VV_ACT_LRELU: with_out(std::integral_constant<int, VV_ACT_LRELU>{}); break;
+        default: with_out(std::integral_constant<int, VV_ACT_NONE>{}); break;
+    }
+    __syncthreads();
+    const int es = out_fp8 ? 1 : 2;
+    const int cpr = CDH_COUT * es / 16;               // 16-byte chunks of this workgroup's half of an output row
+    for (int id = tid; id < 256 * cpr; id += 256) {
+        const int rr = id / cpr, cc = id % cpr;
+        const int od = od0 + (rr >> 6), oh = oh0 + ((rr >> 3) & 7), ow = ow0 + (rr & 7);
+        const size_t vox = ((((((size_t)b << lo) + od) << lo) + oh) << lo) + ow;
+        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(y) + vox * (CD_COUT * es) + nh * CDH_COUT * es + cc * 16) =
+            *reinterpret_cast<const uint4 *>(stage + rr * CDH_SP + cc * 16);
+    }
+}
+
+
 }  // namespace
 
 VV_EXPORT int vv_conv3d_k4s2_direct_supported(int side, int cin, int cout, int dtype) {
@@ -481,11 +706,13 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_direct16h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CDH_LDS);
         return true;
     }();
     (void)attr;
-    const char *se = vv_hook("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16
+    const char *se = vv_hook("VV_CD_SHAPE");          // 16 = v_mfma_f32_16x16x32_bf16 (default), 32 = v_mfma_f32_32x32x16_bf16, 8 = two 4-wave workgroups per CU
     const bool s16 = !se || atoi(se) != 32;
+    const bool half = se && atoi(se) == 8;
     const size_t in_per = (size_t)side * side * side * cin * 2, out_per = (size_t)so * so * so * cout * (out_dtype == VV_FP8 ? 1 : 2);
     const int per = vv_chunk_samples(in_per, batch);
     if (per < 1) return VV_ERR_SHAPE;
@@ -493,7 +720,12 @@ VV_EXPORT int vv_conv3d_k4s2_direct_fwd_io(const void *x, const void *w_packed, 
         const int nb = batch - b0 < per ? batch - b0 : per;
         const __bf16 *xc = reinterpret_cast<const __bf16 *>(reinterpret_cast<const char *>(x) + (size_t)b0 * in_per);
         void *yc = reinterpret_cast<char *>(y) + (size_t)b0 * out_per;
-        if (s16)
+        if (half)
+            VV_LAUNCH(conv_direct16h_kernel, dim3(nb * boxes * 2), dim3(256), CDH_LDS, reinterpret_cast<hipStream_t>(stream), xc,
+                      reinterpret_cast<const __bf16 *>(w_packed), scale, shift, yc, vv_log2(so), (unsigned)((size_t)nb * in_per),
+                      (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0,
+                      vv_hook("VV_CDH_STAGGER") ? atoi(vv_hook("VV_CDH_STAGGER")) : 5, vv_hook("VV_CDH_ABL") ? atoi(vv_hook("VV_CDH_ABL")) : 0);
+        else if (s16)
             VV_LAUNCH(conv_direct16_kernel, dim3(nb * boxes), dim3(512), CD_LDS, reinterpret_cast<hipStream_t>(stream), xc,
                       reinterpret_cast<const __bf16 *>(w_packed), scale, shift, yc, vv_log2(so), (unsigned)((size_t)nb * in_per),
                       (unsigned)((size_t)64 * cin * cout * 2), act, out_dtype == VV_FP8 ? 1 : 0);

@@ -256,7 +256,7 @@ def lint_file(src):
 # depth of each kernel as built today (GPU-tested).  None = not statically bounded (the wait count is selected at run time from
 # several `s_waitcnt`s; the walker cannot tell which paths are feasible).
 PINNED_WAITS = {
-    'conv_direct_kernel': (2, 2), 'conv_direct16_kernel': (2, 2), 'conv_direct_fp8_kernel': (2, 2),
+    'conv_direct_kernel': (2, 2), 'conv_direct16_kernel': (2, 2), 'conv_direct16h_kernel': (2, 1), 'conv_direct_fp8_kernel': (2, 2),
     'convT_direct_kernel': (1, 2), 'convT_direct_fp8_kernel': (1, 2),
     'ctw_kernel': (4, 2), 'ctw16_kernel': (4, 2), 'ctw4_kernel': (4, 2),
     'final_bce_sweep_kernel': (3, 0), 'final_bce_sweepw_kernel': (3, 0), 'final_bce_sweep_fp8_kernel': (3, 0), 'final_bce_mfma_kernel': (0, 0),
@@ -264,7 +264,7 @@ PINNED_WAITS = {
     'sd_kernel': (2, 2), 'wgrad_bf16_kernel': (1, 1), 'wgrad_phase_kernel': (1, 2),
 }
 # kernels whose counted waits were written for a register-resident loop: no scratch, no spills
-NO_SCRATCH = ('conv_direct_kernel', 'conv_direct16_kernel', 'conv_direct_fp8_kernel', 'convT_direct_fp8_kernel', 'ctw_kernel', 'ctw16_kernel',
+NO_SCRATCH = ('conv_direct_kernel', 'conv_direct16_kernel', 'conv_direct16h_kernel', 'conv_direct_fp8_kernel', 'convT_direct_fp8_kernel', 'ctw_kernel', 'ctw16_kernel',
               'final_bce_sweep_kernel', 'final_bce_sweepw_kernel', 'final_bce_sweep_fp8_kernel', 'sd_kernel', 'pg_kernel', 'wgrad_phase_kernel', 'igemm_kernel')
 # kernel family -> (source, VGPR budget): launchers that deal the work items for a fixed number of workgroups per CU.  The first layer's
 # plane form was written for four per CU (128 VGPRs); removing its timing ablations let the register allocator drift to 134 = three per

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae.so')
 # scripts under profiles/microbench/) has its calls routed there WHILE one of the hook variables below is set, and to the release
 # library otherwise -- so everything that does not ask for an override still runs the product.
 HOOKS_LIB_PATH = os.path.join(PKG, 'lib', 'libvoxvae_hooks.so')
-HOOK_VARS = ('VV_CD_SHAPE', 'VV_DIRECT_MT', 'VV_LT_KSLICE', 'VV_SPLIT_TARGET', 'VV_SPLIT_MINCHUNKS', 'VV_NO_KHALVES', 'VV_POSMAJOR_CONV_SIDE',
+HOOK_VARS = ('VV_CD_SHAPE', 'VV_CDH_STAGGER', 'VV_CDH_ABL', 'VV_DIRECT_MT', 'VV_LT_KSLICE', 'VV_SPLIT_TARGET', 'VV_SPLIT_MINCHUNKS', 'VV_NO_KHALVES', 'VV_POSMAJOR_CONV_SIDE',
              'VV_POSMAJOR_CONVT_SIDE', 'VV_STAGES', 'VV_NO_FIRSTCONV', 'VV_WGRAD_F32', 'VV_PG_TARGET', 'VV_CTW_PS', 'VV_CTW_SHAPE',
              'VV_NO_WGRAD_PHASE', 'VV_BN_NB', 'VV_BN_SWEEP', 'VV_FINAL_BCE', 'VV_FIRSTCONV_GATHER', 'VV_FIRSTCONV_WGS', 'VV_FIRSTCONV_NOCHAIN', 'VV_CHUNK_SAMPLES')
 

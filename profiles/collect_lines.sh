@@ -5,6 +5,8 @@ python bench.py --steps 400 --warmup 50 > $O/r04_bf16_b256_bench_unprofiled.json
 python bench.py --steps 20 --warmup 5 > $O/r04_bf16_b256_bench_driver_form.json 2>> $O/err1.log
 python bench.py --steps 400 --warmup 50 --dtype fp8 > $O/r04_fp8_wide_b256_bench.json 2>> $O/err1.log
 python bench.py --steps 400 --warmup 50 --dtype fp8 --fp8-policy all > $O/r04_fp8_all_b256_bench.json 2>> $O/err1.log
+VV_NO_POS_TAIL=1 python bench.py --steps 400 --warmup 50 --cpu-samples 0 > $O/r04_ab_unfused_tail_bf16_b256_bench.json 2>> $O/err1.log
+python bench.py --steps 400 --warmup 50 --cpu-samples 0 > $O/r04_ab_fused_tail_bf16_b256_bench.json 2>> $O/err1.log
 echo 32done
 python bench.py --steps 100 --warmup 20 --voxel 64 --batch 64 > $O/r04_bf16_d64_b64_bench.json 2>> $O/err1.log
 python bench.py --steps 100 --warmup 20 --voxel 64 --batch 64 --dtype fp8 > $O/r04_fp8_wide_d64_b64_bench.json 2>> $O/err1.log

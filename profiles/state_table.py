@@ -8,6 +8,77 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'anytime-3d-reconstructio
 from voxvae import workload, synthetic as syn
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+what = sys.argv[2] if len(sys.argv) > 2 else 'eval'
+
+
+def line_of(name):
+    try:
+        return json.loads(open(os.path.join(HERE, name)).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+if what == 'bench':
+    print('| line (file under `profiles/`) | command | value | ms / step | notes |')
+    print('|---|---|---|---|---|')
+    spec = [('bf16_b256_bench_driver_form', '`python bench.py --steps 20 --warmup 5` (the driver\'s form)', 'reconstructions/s'),
+            ('bf16_b256_bench_unprofiled', '`--steps 400 --warmup 50`', 'reconstructions/s'),
+            ('ab_unfused_tail_bf16_b256_bench', '`VV_NO_POS_TAIL=1`, `--steps 400 --warmup 50` (round-3 chain, same box)', 'reconstructions/s'),
+            ('ab_fused_tail_bf16_b256_bench', 'the same with the fused tail', 'reconstructions/s'),
+            ('fp8_wide_b256_bench', '`--dtype fp8` (policy `wide`)', 'reconstructions/s'),
+            ('fp8_all_b256_bench', '`--dtype fp8 --fp8-policy all` (opt-in, over the IoU bar)', 'reconstructions/s'),
+            ('bf16_d64_b64_bench', '`--voxel 64 --batch 64` (config 5\'s per-GPU shard, bf16)', 'reconstructions/s'),
+            ('fp8_wide_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8` (config 5)', 'reconstructions/s'),
+            ('fp8_all_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8 --fp8-policy all`', 'reconstructions/s'),
+            ('train_bf16_b256_bench_unprofiled', '`--mode train --steps 100 --warmup 20` (config 4\'s per-rank shape)', 'samples/s'),
+            ('launcher_n1_eval', '`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (RCCL group of one rank)', 'reconstructions/s'),
+            ('launcher_n1_train', 'the same with `--mode train`', 'samples/s')]
+    for key, cmd, unit in spec:
+        d = line_of('%s_%s.json' % (rnd, key))
+        if d is None:
+            continue
+        notes = []
+        r = d.get('roofline')
+        if r:
+            notes.append('roofline %s: %.0f %s = %.3f of peak (%s, %.1f us)' % (r.get('bound'), r['achieved'], r['unit'], r['frac'], (r.get('kernel') or '')[:40], 1e3 * r.get('launch_ms', 0)))
+        c = d.get('cpu_baseline')
+        if c:
+            notes.append('cpu_baseline %.1f %s on %d cores (%s)' % (c['value'], c['unit'], c['cores'], c['kind']))
+        p_ = (d.get('parity') or {})
+        if 'iou_delta' in p_:
+            notes.append('IoU delta %.1e' % p_['iou_delta'])
+        h = d.get('h2d_inclusive')
+        if h:
+            notes.append('host arrays %.0f k/s (bit-packed in %.0f k, + uint8 out %.0f k)' % (h['value'] / 1e3, h['bit_packed_input']['value'] / 1e3,
+                                                                                        h['bit_packed_input']['uint8_occupancy_return']['value'] / 1e3))
+        print('| `%s_%s.json` | %s | **%.1f k %s** | %.4f | %s |' % (rnd, key, cmd, d['value'] / 1e3, unit, d['ms_per_step'], '; '.join(notes)))
+    sys.exit(0)
+
+if what == 'train':
+    rows = list(csv.DictReader(open(os.path.join(HERE, rnd + '_train_bf16_b256_kernel_stats.csv'))))
+    steps = 25.0
+    groups = [('forward + data-gradient convolutions', ('conv_direct', 'ctw16', 'sd_kernel', 'pg_kernel', 'pg_reduce', 'first_conv', 'igemm', 'final_bce')),
+              ('weight gradients', ('wgrad',)),
+              ('BatchNorm: batch statistics (reduce + finalize)', ('bn_reduce_kernel<0', 'bn_stats_finalize')),
+              ('BatchNorm: apply + activation', ('bn_act_fwd',)),
+              ('BatchNorm: backward (reduce + finalize + apply)', ('bn_reduce_kernel<1', 'bn_bwd_finalize', 'bn_act_bwd')),
+              ('Adam (one launch, 742 MB)', ('adam',)),
+              ('weight packs (per step: the weights change)', ('pack', 'fold_bn')),]
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    used = set()
+    print('| share of the step (`%s_train_bf16_b256_kernel_stats.csv`, rocprofv3, 25 steps) | ms / step | %% of GPU time | launches / step |' % rnd)
+    print('|---|---|---|---|')
+    for name, subs in groups:
+        sel = [r for r in rows if any(s_ in r['Name'] for s_ in subs) and r['Name'] not in used]
+        used |= set(r['Name'] for r in sel)
+        t = sum(float(r['TotalDurationNs']) for r in sel)
+        print('| %s | %.3f | %.1f | %.0f |' % (name, t / steps / 1e6, 100 * t / tot, sum(int(r['Calls']) for r in sel) / steps))
+    rest = [r for r in rows if r['Name'] not in used]
+    t = sum(float(r['TotalDurationNs']) for r in rest)
+    print('| everything else (losses, latent, dense layers, copies) | %.3f | %.1f | %.0f |' % (t / steps / 1e6, 100 * t / tot, sum(int(r['Calls']) for r in rest) / steps))
+    print('| **sum of kernel time** | **%.3f** | 100 | %.0f |' % (tot / steps / 1e6, sum(int(r['Calls']) for r in rows) / steps))
+    sys.exit(0)
+
 B = 256
 cfg = syn.make_config(32, 64, True)
 macs = {n: v for n, v, _ in workload.layer_macs(cfg)}

@@ -508,7 +508,7 @@ def test_convT3d_k4s2_direct(L, B, side, variant, monkeypatch):
     _check(y, ref, 'bf16', 'convT3d_k4s2_direct')
 
 
-@pytest.mark.parametrize('shape', [16, 32])            # MFMA shape: 16x16x32 (default) / 32x32x16
+@pytest.mark.parametrize('shape', [16, 32, 8])         # MFMA shape: 16x16x32 (default) / 32x32x16 / 8 = 16x16x32 as two 4-wave workgroups per CU
 @pytest.mark.parametrize('B,side,act', [(2, 16, 1), (1, 32, 1), (3, 16, 0), (5, 16, 2)])
 def test_conv3d_k4s2_direct(L, B, side, act, shape, monkeypatch):
     monkeypatch.setenv('VV_CD_SHAPE', str(shape))
@@ -818,13 +818,13 @@ def test_widest_layers_full_batch_forms_agree(L, monkeypatch):
     wp = torch.empty(128, 64 * 64, dtype=torch.bfloat16, device=DEV)
     L.call('vv_pack_conv_k4', L.ptr(w2), L.ptr(wp), 64, 128, L.VV_BF16, _st())
     outs = []
-    for shape in ('16', '32'):
+    for shape in ('16', '32', '8'):
         monkeypatch.setenv('VV_CD_SHAPE', shape)
         y = torch.full((B, 8, 8, 8, 128), float('nan'), dtype=torch.bfloat16, device=DEV)
         L.call('vv_conv3d_k4s2_direct_fwd', L.ptr(x2), L.ptr(wp), L.ptr(sc), L.ptr(sh), L.ptr(y), B, 16, 64, 128, 1, L.VV_BF16, _st())
         torch.cuda.synchronize()
         outs.append(y)
-    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and not torch.isnan(outs[0].float()).any()
 
 
 def test_first_and_last_layer_full_batch_cross_forms(L, monkeypatch):
