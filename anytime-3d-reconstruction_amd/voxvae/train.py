@@ -73,6 +73,8 @@ class GradBuckets:
         self._wire_bufs = None       # wire='bf16': per bucket (bf16 send copy, received shards [world, shard], reduced shard, gathered)
         self._comm_stream = None
         self.always_reduce = False   # True: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)
+        self.producer_streams = ()   # CUDA streams that write gradients (Trainer: launch stream + weight-gradient stream): a bucket's
+                                     # collective is ordered behind ALL of them, whichever stream its last member was enqueued on
         self.profile = None          # a list: finish() appends (event before, event after) -- the EXPOSED collective time
         self.begin_step()
 
@@ -126,6 +128,11 @@ class GradBuckets:
         self.launch_order.append(b)
         if self._distributed(group):
             import torch.distributed as dist
+            if self.buckets[b].is_cuda and self.producer_streams:
+                cur = torch.cuda.current_stream(self.buckets[b].device)
+                for ps in self.producer_streams:
+                    if ps != cur:
+                        cur.wait_stream(ps)
             if self.wire == 'bf16':
                 self._works[b] = self._launch_bf16(b, group, dist)
             else:
@@ -221,12 +228,21 @@ class Trainer:
         self.t = 0
         self.debug = None          # set to a dict to capture intermediate tensors of the next step (tests)
         self.overlap = True        # launch each gradient bucket's all-reduce as soon as its last member is enqueued
+        # Weight gradients on a SECOND stream (round 4, opt-in: VOXVAE_WGRAD_STREAM=1): wgrad(layer i) needs only dL/d(conv out of i) and
+        # the layer's input, and nothing downstream needs it before Adam, so it can fork off the chain while that continues with the next
+        # layer's BatchNorm backward sweeps (HBM streams without LDS beside MFMA / LDS work).  Measured on MI355X it is SLOWER: 2.74 against
+        # 2.65 ms per step, the weight-gradient kernels take 0.28 instead of 0.13 ms each beside the sweeps and nothing is gained back
+        # (profiles/r04_train_wgrad_stream_ab.json) -- the same sign as round 3's side-stream weight packing.  Bit-identical results.
+        self.wgrad_stream = None
+        if str(self.dev).startswith('cuda') and os.environ.get('VOXVAE_WGRAD_STREAM', '0') == '1':
+            self.wgrad_stream = torch.cuda.Stream(device=self.dev)
         self.ws = E._Workspace(self.dev)
         names = [] if enc is None else [('enc/' + k, v.shape) for k, v in enc.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         names += [('dec/' + k, v.shape) for k, v in dec.params.items() if not k.endswith(('moving_mean', 'moving_variance'))]
         # backward order: decoder tail first ... encoder head last
         self.order = list(reversed(names))
         self.grads = GradBuckets(self.order, self.dev, wire=grad_wire or os.environ.get('VOXVAE_GRAD_WIRE', 'f32'), world_size=self.world)
+        self._side_used = False
         self.m = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
         self.v = {n: torch.zeros(s, dtype=torch.float32, device=self.dev) for n, s in names}
 
@@ -325,8 +341,27 @@ class Trainer:
         ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(rows, m, n))
         L.call('vv_wgrad_dense', L.ptr(a), L.ptr(g), L.ptr(out), rows, m, n, m, self._dt(a), self._dt(g), L.ptr(ws), ws.numel(), _st())
 
-    def _wgrad_conv(self, src, g, out, batch, side, cin, cout):
+    def _wgrad_conv(self, src, g, out, batch, side, cin, cout, ready=None):
+        """Weight gradient of a stride-2 layer into `out` (a view of a gradient bucket).  ready: the gradient's name -- reported to
+        the buckets from the stream the kernel was enqueued on (a bucket's all-reduce is ordered behind that stream)."""
         o = side // 2
+        ws_stream = getattr(self, 'wgrad_stream', None)
+        if ws_stream is None:
+            self._wgrad_conv_launch(src, g, out, batch, side, cin, cout, o)
+            if ready:
+                self._ready(ready)
+            return
+        main = torch.cuda.current_stream(self.dev)
+        ws_stream.wait_stream(main)
+        for t in (src, g):
+            t.record_stream(ws_stream)               # allocated on the launch stream, read on this one
+        with torch.cuda.stream(ws_stream):
+            self._wgrad_conv_launch(src, g, out, batch, side, cin, cout, o)
+            if ready:
+                self._ready(ready)
+        self._side_used = True
+
+    def _wgrad_conv_launch(self, src, g, out, batch, side, cin, cout, o):
         ws = self.ws.get(L.load().vv_wgrad_workspace_bytes(batch * o ** 3, 64 * cin, cout))
         tm = getattr(self, 'timer', None)            # bench.py's roofline leg: HIP events around the launch, on its stream
         tok = tm.begin('wgrad:%d:%d:%d' % (side, cin, cout)) if tm is not None else None
@@ -408,6 +443,7 @@ class Trainer:
         self.enc.ensure_packed(fold=False)
         self.dec.ensure_packed(fold=False)      # (packing the decoder on a side stream under the encoder's forward was measured: +0.11 ms per step)
         self.grads.begin_step()
+        self._set_producer_streams()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
         enc_out, est = self._encoder_forward(x, B)
@@ -416,6 +452,16 @@ class Trainer:
         self._apply()
         return kl, stats, metrics
 
+    def _join_wgrad(self):
+        """The launch stream waits for the weight-gradient stream: every weight gradient is in its bucket."""
+        if getattr(self, 'wgrad_stream', None) is not None and self._side_used:
+            torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
+            self._side_used = False
+
+    def _set_producer_streams(self):
+        if getattr(self, 'wgrad_stream', None) is not None:
+            self.grads.producer_streams = (torch.cuda.current_stream(self.dev), self.wgrad_stream)
+
     def step_from_latent(self, enc_out, y, eps=None, drop_mask=None, drop_scale=1.0, l2=0.0):
         """Decoder-only step for the image -> 3D model (nolbo.py:786-833): enc_out [B, 2L] (mean | logVar) comes from a 2D
         encoder owned by the caller.  Trains the decoder and returns (loss_kl, stats, metrics, d total / d enc_out) so the
@@ -423,12 +469,14 @@ class Trainer:
         regularisers when the caller's loss includes them."""
         self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
+        self._set_producer_streams()
         overlap, self.overlap = self.overlap, self.overlap and l2 == 0      # the l2 terms are added before the cross-rank sum
         B = enc_out.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         kl, stats, metrics, de = self._latent_decoder(enc_out, y, eps, drop_mask, drop_scale, B, inv_gb)
         self.overlap = overlap
         if l2 > 0:      # + sum(decoder.losses) in the total loss (nolbo.py:819-823): d/dw of l2 * sum(w^2)
+            self._join_wgrad()
             for name, _ in self.order:
                 if name.endswith('/kernel') or name == 'dec/dense/bias':
                     self._g(name).add_(self._p(name), alpha=2.0 * l2 / self.world)
@@ -446,6 +494,7 @@ class Trainer:
         self.enc.ensure_packed(fold=False)
         self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
+        self._set_producer_streams()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         enc_out, est = self._encoder_forward(x, B)
@@ -575,8 +624,7 @@ class Trainer:
         dlogit = self._empty(B, D, D, D, 1)
         L.call('vv_bce_bwd', L.ptr(probs), L.ptr(y), L.ptr(dlogit), B, D ** 3, 0.6, 1e-7, inv_gb, st)
         cl = fd[nd - 1]
-        self._wgrad_conv(dlogit, dh_[-1], self._g('dec/convT%d/kernel' % nd), B, D, 1, cl)        # [64 taps][cl] = Keras [4,4,4,1,cl]
-        self._ready('dec/convT%d/kernel' % nd)
+        self._wgrad_conv(dlogit, dh_[-1], self._g('dec/convT%d/kernel' % nd), B, D, 1, cl, ready='dec/convT%d/kernel' % nd)   # [64 taps][cl] = Keras [4,4,4,1,cl]
         w5p = self._aempty(cl, 64)
         L.call('vv_pack_conv_k4', L.ptr(w5), L.ptr(w5p), 1, cl, dt, st)
         dh = self._aempty(B, side, side, side, cl)
@@ -585,8 +633,7 @@ class Trainer:
             cin, cout = fd[i - 1], fd[i]
             dcv = self._bn_bwd(dc_[i], dh, dbn[i], B * side ** 3, 'dec/bnT%d/gamma' % i, 'dec/bnT%d/beta' % i, act)
             wk = dec.params['convT%d/kernel' % i]            # Keras [4,4,4,cout,cin]
-            self._wgrad_conv(dcv, dh_[i - 1], self._g('dec/convT%d/kernel' % i), B, side, cout, cin)
-            self._ready('dec/convT%d/kernel' % i)
+            self._wgrad_conv(dcv, dh_[i - 1], self._g('dec/convT%d/kernel' % i), B, side, cout, cin, ready='dec/convT%d/kernel' % i)
             dh = self._conv(dcv, wk, B, side, cout, cin)     # read as a forward conv kernel [4,4,4,Cin_c=cout,Cout_c=cin]
             side //= 2
         # D1 (dense panel over the S^3 seed)
@@ -636,19 +683,18 @@ class Trainer:
             cin, cout = fe[i - 1], fe[i]
             dcv = self._bn_bwd(ec[i], dh, ebn[i], B * side ** 3, 'enc/bn%d/gamma' % i, 'enc/bn%d/beta' % i, act)
             wk = enc.params['conv%d/kernel' % i]             # Keras [4,4,4,cin,cout]
-            self._wgrad_conv(eh[i - 1], dcv, self._g('enc/conv%d/kernel' % i), B, 2 * side, cin, cout)
-            self._ready('enc/conv%d/kernel' % i)
+            self._wgrad_conv(eh[i - 1], dcv, self._g('enc/conv%d/kernel' % i), B, 2 * side, cin, cout, ready='enc/conv%d/kernel' % i)
             dh = self._convT(dcv, wk, B, side, cout, cin)    # read as a transposed kernel [4,4,4,Cout_T=cin,Cin_T=cout]
             side *= 2
         dcv = self._bn_bwd(ec[0], dh, ebn[0], B * side ** 3, 'enc/bn0/gamma', 'enc/bn0/beta', act)
-        self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0])
-        self._ready('enc/conv0/kernel')
+        self._wgrad_conv(x, dcv, self._g('enc/conv0/kernel'), B, D, 1, fe[0], ready='enc/conv0/kernel')
         if self.debug is not None:
             self.debug.update({'h_enc': eh, 'c_enc': ec})
 
     def _apply(self):
         # ---------------- cross-rank gradient sum, then Adam on every replica
         st = _st()
+        self._join_wgrad()
         self.grads.finish(self.group)
         self.t += 1
         lr_t = self.lr * (1.0 - ADAM_B2 ** self.t) ** 0.5 / (1.0 - ADAM_B1 ** self.t)

@@ -89,6 +89,27 @@ def test_two_steps_loss_decreases_and_state_advances():
     assert all(np.isfinite(l1))
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_weight_gradient_stream_is_bit_identical(dtype, monkeypatch):
+    """The opt-in second stream for the weight gradients (Trainer.wgrad_stream, VOXVAE_WGRAD_STREAM=1; measured slower and off by default,
+    profiles/r04_train_wgrad_stream_ab.json): three steps give the same weights, moments and losses bit for bit as the one-stream step --
+    the fork / join events and record_stream calls order every reader behind its writer."""
+    res = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('VOXVAE_WGRAD_STREAM', flag)
+        cfg, ep, dp, model, x, eps = _setup(32, 64, True, 16, seed=5, dtype=dtype)
+        losses = [[float(v) for v in model.fit((x, x), _eps=eps)] for _ in range(3)]
+        torch.cuda.synchronize()
+        tr = model._trainer
+        assert (tr.wgrad_stream is not None) == (flag == '1')
+        res.append((losses, {k: v.clone() for k, v in model._enc_eng.params.items()}, {k: v.clone() for k, v in model._dec_eng.params.items()},
+                    {k: v.clone() for k, v in tr.m.items()}))
+    assert res[0][0] == res[1][0]
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2]), (res[0][3], res[1][3])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_decoder_only_step_matches_full_step():
     """Trainer.step_from_latent (image -> 3D model, nolbo.py:786-833) is the decoder + latent part of the full step: fed
     the full step's encoder output it must produce the same decoder gradients and the same d loss / d enc_out."""
