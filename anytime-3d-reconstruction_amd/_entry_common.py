@@ -46,6 +46,7 @@ def parse(description, train=False):
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--device-data', action='store_true', help='keep the split in HBM as packed bits (deviceDataLoader)')
     ap.add_argument('--packed-data', action='store_true', help='host loader that keeps the split as bits and serves PackedVoxels batches (1 bit per voxel over PCIe)')
+    ap.add_argument('--pipeline', type=int, default=1, help='test_modelnet_VAE.py: batches in flight (voxvae.streams.HostPipeline); 1 = the reference\'s synchronous loop')
     ap.add_argument('--dump-dir', default=None, help='test_modelnet_VAE.py: save <missing_pr>_cl_label/_gt/_pred.npy here (reference :159-165)')
     return ap.parse_args()
 

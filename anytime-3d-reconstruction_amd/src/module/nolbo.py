@@ -139,7 +139,8 @@ class _ModelnetBase(object):
         input_images, output_images, category_list = inputs
         from voxvae.hostio import PackedVoxels as _PV
         if missing_prob == 0.0 and isinstance(input_images, (np.ndarray, _PV)) and isinstance(output_images, (np.ndarray, _PV)):
-            out = self._getEval_host_chunked(input_images, output_images, category_list, category_vectors, _eps)
+            out = self._getEval_host_chunked(input_images, output_images, category_list, category_vectors, _eps,
+                                             lazy=getattr(self, '_lazy_host', False))
             if out is not None:
                 return out
         x, y = self._dev_pair(input_images, output_images)
@@ -178,13 +179,16 @@ class _ModelnetBase(object):
         self._z_category_corrected = DeviceArray(zc)
         return res + (DeviceArray(pred_c), DeviceArray(mc[0]), DeviceArray(mc[1]), DeviceArray(mc[2]), DeviceArray(acc_c[0]))
 
-    def _getEval_host_chunked(self, input_images, output_images, category_list, category_vectors, _eps):
+    def _getEval_host_chunked(self, input_images, output_images, category_list, category_vectors, _eps, lazy=False):
         """getEval(missing_prob=0) on HOST arrays (the reference's calling convention, test_modelnet_VAE.py:114-130) as a
         pipeline over sample ranges: the upload of chunk k+1 runs under the kernels of chunk k, the download of chunk k's
         prediction (into a recycled pinned block) under the kernels of chunk k+1 -- two streams, this model's one pair of
         engines (per-stream workspaces).  Every kernel of the path treats samples independently with a batch-size-independent
         summation order, so the result is the whole-batch result bit for bit (tests/test_gpu_api.py).  Returns None when the
-        batch is too small to split or no pinned block is available (the caller then takes the plain path)."""
+        batch is too small to split or no pinned block is available (the caller then takes the plain path).
+        lazy (voxvae.streams.HostPipeline): nothing here waits for the device -- the prediction's download is enqueued behind the
+        kernels and the returned HostPrediction waits for it on first access; ONE pass over the whole batch by default (the overlap
+        comes from the NEXT batch, issued by the pipeline on another stream, and whole-batch kernels fill the chip)."""
         from voxvae import hostio as _H
         if getattr(self, '_enc_eng', None) is None or input_images.ndim != 5:
             return None                                  # the image -> 3D model: its inputs are images / head outputs, not voxel grids
@@ -192,7 +196,7 @@ class _ModelnetBase(object):
         # Two chunks pay when the download is the long pole (float32 probabilities: 33.6 MB at the PCIe rate = 0.60 ms beside 0.49 ms of
         # kernels); with the uint8 occupancy return (0.16 ms) one whole-batch pass is faster than two half-batch ones, whose
         # one-workgroup-per-sample kernels fill half the chip each (profiles/r04_host_chunks.json: 0.94 against 1.05 ms per call)
-        nchunk = int(os.environ.get('VV_HOST_CHUNKS', '2' if _H.prediction_host_dtype() == 'float32' else '1'))
+        nchunk = int(os.environ.get('VV_HOST_CHUNKS', '1' if lazy else ('2' if _H.prediction_host_dtype() == 'float32' else '1')))
 
         def usable(a):      # a float32 C-contiguous array, or a bit-packed host batch (voxvae/hostio.py: 1 bit per voxel over PCIe)
             return isinstance(a, _H.PackedVoxels) or (a.dtype == np.float32 and a.flags['C_CONTIGUOUS'])
@@ -200,7 +204,7 @@ class _ModelnetBase(object):
         def upload(a, lo, hi):
             return a.to_device(dev, lo, hi) if isinstance(a, _H.PackedVoxels) else torch.from_numpy(a[lo:hi]).to(dev)
 
-        if nchunk < 2 or B < 64 * nchunk or not usable(input_images):
+        if (nchunk < 2 and not lazy) or nchunk < 1 or B < 64 * nchunk or not usable(input_images):
             return None
         same = output_images is input_images
         if not same and (not usable(output_images) or tuple(output_images.shape) != tuple(input_images.shape)):
@@ -211,8 +215,12 @@ class _ModelnetBase(object):
             return None
         dev = self._device
         main = torch.cuda.current_stream(dev)
-        if getattr(self, '_io_streams', None) is None or len(self._io_streams) != nchunk:
-            self._io_streams = [torch.cuda.Stream(device=dev) for _ in range(nchunk)]
+        if lazy and nchunk == 1:
+            io_streams = [main]                     # the pipeline gives every batch in flight its own stream: no fork needed
+        else:
+            if getattr(self, '_io_streams', None) is None or len(self._io_streams) != nchunk:
+                self._io_streams = [torch.cuda.Stream(device=dev) for _ in range(nchunk)]
+            io_streams = self._io_streams
         Lz = self._latent_dim
         eps = None
         if self._variational:
@@ -222,9 +230,10 @@ class _ModelnetBase(object):
         self._dec_eng.ensure_packed()
         bounds = [B * k // nchunk // 4 * 4 for k in range(nchunk)] + [B]
         zs, stats, preds = [], [], []
-        for k, s in enumerate(self._io_streams):
+        for k, s in enumerate(io_streams):
             lo, hi = bounds[k], bounds[k + 1]
-            s.wait_stream(main)
+            if s is not main:
+                s.wait_stream(main)
             with torch.cuda.stream(s):
                 # pageable source, synchronous copy at the PCIe rate.  (Staging the chunk through a pinned block to make the upload
                 # asynchronous was measured and is NOT used: an async host -> device copy issued beside running kernels took 10-50x
@@ -237,15 +246,21 @@ class _ModelnetBase(object):
             for t in (z, st_, pred):
                 t.record_stream(main)
             zs.append(z); stats.append(st_); preds.append(pred)
-        for s in self._io_streams:
-            main.wait_stream(s)
+        for s in io_streams:
+            if s is not main:
+                main.wait_stream(s)
         z = torch.cat(zs, dim=0)
         m = _E.shape_metrics(torch.cat(stats, dim=0))
         _, acc = self._category_acc(z, cats, onehot)
         self._z_category = DeviceArray(z)
-        for s in self._io_streams:                  # the host array is handed out: its downloads must have landed
-            s.synchronize()
-        return (_H.HostPrediction(host, preds), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]), 0, 0, 0, 0, 0)
+        ready = None
+        if lazy:                                    # the caller's stream has joined every chunk stream above: one event covers the downloads
+            ready = [torch.cuda.Event()]
+            ready[0].record(main)
+        else:
+            for s in io_streams:                    # the host array is handed out: its downloads must have landed
+                s.synchronize()
+        return (_H.HostPrediction(host, preds, ready), DeviceArray(m[0]), DeviceArray(m[1]), DeviceArray(m[2]), DeviceArray(acc[0]), 0, 0, 0, 0, 0)
 
     def _train_helper(self):
         from voxvae import train as _T

@@ -195,10 +195,19 @@ def pack_voxels(x, threshold=0.5):
 class HostPrediction(object):
     """What the chunked getEval returns for `pred`: the host array is already there (its download ran under the kernels of the
     next chunk); the device chunks are kept for callers that want the tensor."""
-    __slots__ = ('host', 'chunks', '_t', '_handed_out')
+    __slots__ = ('host', 'chunks', '_t', '_handed_out', '_ready')
 
-    def __init__(self, host, chunks):
-        self.host, self.chunks, self._t, self._handed_out = host, chunks, None, False
+    def __init__(self, host, chunks, ready=None):
+        """ready: CUDA events the downloads complete behind (the pipelined form, voxvae.streams.HostPipeline): the first access to the
+        host array waits for them; None = the array is complete (the synchronous getEval)."""
+        self.host, self.chunks, self._t, self._handed_out, self._ready = host, chunks, None, False, ready
+
+    def wait(self):
+        if self._ready:
+            for e in self._ready:
+                e.synchronize()
+            self._ready = None
+        return self
 
     @property
     def shape(self):
@@ -218,6 +227,7 @@ class HostPrediction(object):
         return self.t
 
     def numpy(self):
+        self.wait()
         return self._view()
 
     def __array__(self, dtype=None, copy=None):
@@ -228,6 +238,7 @@ class HostPrediction(object):
         `pred[idx]`, `np.asarray(pred)`, a second `np.array(pred)` -- sees the same memory through READ-ONLY views (later np.array
         calls get real copies), so nothing can be changed through them behind the first caller's back; an in-place edit by the first
         caller of its own array does show in those views.  A different dtype always copies."""
+        self.wait()
         if dtype is not None and np.dtype(dtype) != self.host.dtype:
             return self.host.astype(dtype)
         if copy is False:
@@ -248,6 +259,7 @@ class HostPrediction(object):
         return self.host.shape[0]
 
     def __getitem__(self, idx):
+        self.wait()
         return self._view()[idx]
 
     def __repr__(self):

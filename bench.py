@@ -593,7 +593,40 @@ def main():
         hostio.set_prediction_host_dtype('uint8')
         dtp8 = time_steps(host_call_packed, 20, 5)
         hostio.set_prediction_host_dtype('float32')
-        h2d = {'value': a.batch / dth, 'unit': 'reconstructions/s', 'ms_per_call': 1e3 * dth,
+        # the same loop with the batches overlapped (voxvae.streams.HostPipeline: submit batch k + 1 .. k + 2 before converting batch k;
+        # every getEval still takes host arrays and every prediction still ends as a numpy array on the host)
+        import collections
+        from voxvae.streams import HostPipeline
+
+        def pipelined(xin, n=60, depth=3):
+            pipe, pend = HostPipeline(model, depth), collections.deque()
+
+            def consume(p_):
+                out = p_.get()
+                return np.array(out[0]), float(out[1])
+            for _ in range(2 * depth):
+                pend.append(pipe.submit(inputs=(xin, xin, oh), category_vectors=cats, _eps=epsh))
+            while pend:
+                consume(pend.popleft())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pend.append(pipe.submit(inputs=(xin, xin, oh), category_vectors=cats, _eps=epsh))
+                if len(pend) == depth:
+                    consume(pend.popleft())
+            while pend:
+                consume(pend.popleft())
+            return (time.perf_counter() - t0) / n
+
+        pl = {}
+        for key, xin, pdt in (('float32_in_float32_out', xh, 'float32'), ('bit_packed_in_float32_out', xp, 'float32'), ('bit_packed_in_uint8_out', xp, 'uint8')):
+            hostio.set_prediction_host_dtype(pdt)
+            dtq = pipelined(xin)
+            pl[key] = {'value': a.batch / dtq, 'ms_per_batch': 1e3 * dtq}
+        hostio.set_prediction_host_dtype('float32')
+        pl['what'] = ('HostPipeline(model, depth=3): getEval(host arrays) enqueued for batch k + 1, k + 2 before np.array(pred) of batch k; 60 batches; '
+                      'bit-identical to the synchronous call')
+        h2d = {'value': a.batch / dth, 'unit': 'reconstructions/s', 'ms_per_call': 1e3 * dth, 'pipelined': pl,
                'bit_packed_input': {'value': a.batch / dtp, 'ms_per_call': 1e3 * dtp, 'uint8_occupancy_return': {'value': a.batch / dtp8, 'ms_per_call': 1e3 * dtp8},
                                     'what': 'getEval(PackedVoxels x, x, one-hot) -> np.array(pred): the batch is kept as 1 bit per voxel on the host (made once where the '
                                             'data enters: dataLoader(packed=True) / hostio.pack_voxels), %.2f MB host->device + vv_unpack_bits_gather; float32 '

@@ -663,6 +663,65 @@ def test_eval_step_as_hip_graph_is_identical():
         assert all(torch.equal(a, b) for a, b in zip(ref, out))
 
 
+def test_host_pipeline_overlapped_batches_are_bit_identical():
+    """voxvae.streams.HostPipeline (round 4): the reference's loop with batches k + 1, k + 2 enqueued before batch k is converted.  Five
+    DIFFERENT batches through a depth-3 pipeline give, batch by batch, the bits of the synchronous getEval on the same host arrays --
+    float32 and bit-packed input, float32 and uint8 prediction, and a weight change between two submits is picked up."""
+    import collections
+    import voxvae
+    from voxvae import hostio
+    from voxvae import synthetic as syn
+    from voxvae.streams import HostPipeline, PendingEval
+    voxvae.set_default_dtype('bf16')
+    voxvae.set_default_device('cuda:0')
+    import src.module.nolbo as nolbo
+    cfg = syn.make_config(32, 64, True)
+    m = nolbo.nolboSingleObject_modelnet_category_VAE(nolbo_structure=cfg)
+    m._encoder.set_weights_dict(syn.make_encoder_params(cfg['encoder']))
+    m._decoder.set_weights_dict(syn.make_decoder_params(cfg['decoder']))
+    B, nb = 128, 5
+    xs = [syn.make_voxels(B, 32, seed=40 + i) for i in range(nb)]
+    es = [syn.make_eps(B, 64, seed=60 + i) for i in range(nb)]
+    oh, cats = syn.make_onehot(B, 40), syn.make_category_vectors(40, 64)
+    try:
+        for packed, pdt in ((False, 'float32'), (True, 'float32'), (True, 'uint8')):
+            hostio.set_prediction_host_dtype(pdt)
+            ins = [hostio.pack_voxels(x) if packed else x for x in xs]
+            want = []
+            for x, e in zip(ins, es):
+                o = m.getEval(inputs=(x, x, oh), category_vectors=cats, missing_prob=0.0, _eps=e)
+                want.append((np.array(o[0]).copy(), [float(v) for v in o[1:5]]))
+            pipe, pend, got = HostPipeline(m, depth=3), collections.deque(), []
+            for x, e in zip(ins, es):
+                p = pipe.submit(inputs=(x, x, oh), category_vectors=cats, _eps=e)
+                assert isinstance(p, PendingEval)
+                pend.append(p)
+                if len(pend) == pipe.depth:
+                    o = pend.popleft().get()
+                    got.append((np.array(o[0]), [float(v) for v in o[1:5]]))
+            while pend:
+                o = pend.popleft().get()
+                got.append((np.array(o[0]), [float(v) for v in o[1:5]]))
+            assert len(got) == nb
+            for (pw, sw), (pg, sg) in zip(want, got):
+                assert pg.dtype == pw.dtype and pg.shape == pw.shape
+                np.testing.assert_array_equal(pg, pw)
+                np.testing.assert_allclose(sg, sw, rtol=1e-6)
+        # a weight change between submits: the batch submitted after it sees the new weights (repacked with nothing in flight)
+        hostio.set_prediction_host_dtype('float32')
+        pipe = HostPipeline(m, depth=2)
+        p0 = pipe.submit(inputs=(xs[0], xs[0], oh), category_vectors=cats, _eps=es[0])
+        dp2 = syn.make_decoder_params(cfg['decoder'], seed=77)
+        m._decoder.set_weights_dict(dp2)
+        p1 = pipe.submit(inputs=(xs[0], xs[0], oh), category_vectors=cats, _eps=es[0])
+        a0, a1 = np.array(p0.get()[0]), np.array(p1.get()[0])
+        ref1 = np.array(m.getEval(inputs=(xs[0], xs[0], oh), category_vectors=cats, missing_prob=0.0, _eps=es[0])[0])
+        np.testing.assert_array_equal(a1, ref1)
+        assert not np.array_equal(a0, a1)
+    finally:
+        hostio.set_prediction_host_dtype('float32')
+
+
 def test_host_array_pipeline_is_bit_identical_and_recycles_pinned_blocks():
     """getEval on HOST arrays (the reference's calling convention, test_modelnet_VAE.py:114-130) runs as a two-chunk pipeline on
     two streams with the prediction downloaded into a recycled pinned block (voxvae/hostio.py).  Must hold: the same bits as
