@@ -707,6 +707,22 @@ def test_host_pipeline_overlapped_batches_are_bit_identical():
                 assert pg.dtype == pw.dtype and pg.shape == pw.shape
                 np.testing.assert_array_equal(pg, pw)
                 np.testing.assert_allclose(sg, sw, rtol=1e-6)
+        # the two-pass evaluation (missing_prob > 0: device-resident plain path, second decoder pass) through the pipeline
+        hostio.set_prediction_host_dtype('float32')
+        rng = np.random.default_rng(3)
+        masks = [(rng.random((B, 64)) > 0.9).astype(np.float32) for _ in range(3)]
+        e2s = [syn.make_eps(B, 64, seed=90 + i) for i in range(3)]
+        want2 = []
+        for i in range(3):
+            o = m.getEval(inputs=(xs[i], xs[i], oh), category_vectors=cats, missing_prob=0.9, _eps=es[i], _mask=masks[i], _eps2=e2s[i])
+            want2.append((np.array(o[0]).copy(), np.array(o[5]).copy(), [float(v) for v in o[1:5] + o[6:10]]))
+        pipe = HostPipeline(m, depth=3)
+        ps = [pipe.submit(inputs=(xs[i], xs[i], oh), category_vectors=cats, missing_prob=0.9, _eps=es[i], _mask=masks[i], _eps2=e2s[i]) for i in range(3)]
+        for (pw, cw, sw), p_ in zip(want2, ps):
+            o = p_.get()
+            np.testing.assert_array_equal(np.array(o[0]), pw)
+            np.testing.assert_array_equal(np.array(o[5]), cw)
+            np.testing.assert_allclose([float(v) for v in o[1:5] + o[6:10]], sw, rtol=1e-6)
         # a weight change between submits: the batch submitted after it sees the new weights (repacked with nothing in flight)
         hostio.set_prediction_host_dtype('float32')
         pipe = HostPipeline(m, depth=2)
