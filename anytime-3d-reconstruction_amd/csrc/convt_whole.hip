@@ -269,10 +269,13 @@ __global__ __launch_bounds__(512, 1) void ctw_kernel(const __bf16 *__restrict__ 
     acc[COT][CT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&F[4 + COT]),                          \
                                                            *reinterpret_cast<const bf16x8 *>(&F[CT]), acc[COT][CT], 0, 0, 0)
 
-template <int ACT>
+// STATS (round 4, the training step's forward pass): also leaves the per-workgroup column sums (sum, sum of squares per output channel, of the
+// bf16 values it stores) as partial[(workgroup * 2 + {0, 1}) * 64 + channel] -- the layout of bn_reduce_kernel's partials, so
+// vv_bn_finalize_stats turns them into the batch statistics and the 134 MB statistics sweep over this layer's output is not run.
+template <int ACT, bool STATS = false>
 __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       __bf16 *__restrict__ y, int npar) {
+                                                       __bf16 *__restrict__ y, int npar, float *__restrict__ partial = nullptr) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -335,6 +338,9 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 st1[4], st2[4];                            // STATS: this lane's running sum / sum of squares of channels 16 cot + 4 q .. + 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { st1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; st2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // ---- epilogue of one parity: lane (r, q) holds channels 16 cot + 4 q .. + 3 of cell 16 ct + r.  v_permlane16_swap of
     // the channel tiles (2c, 2c+1) gives every lane 8 consecutive channels: q = 0: tile 2c ch 0..7, 1: tile 2c+1 ch 0..7,
@@ -358,6 +364,11 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
                     bf16x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = static_cast<__bf16>(t[e]);
+                    if (STATS) {                     // of the ROUNDED values: what the BatchNorm that follows normalises
+                        const f32x4 f = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                        st1[cot] += f;
+                        st2[cot] += f * f;
+                    }
                     acc[cot][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                     o[h][ct] = *reinterpret_cast<const u32x2 *>(&v);
                 }
@@ -451,6 +462,35 @@ __global__ __launch_bounds__(512, 1) void ctw16_kernel(const __bf16 *__restrict_
     }
     CW16_WAIT(P, 0);
     cw_wait_vm<0>();
+    if (STATS) {
+        // lanes (r, q), r = 0..15, hold the same channels for different cells: sum over r, then over the waves through LDS (free now)
+#pragma unroll
+        for (int cot = 0; cot < 4; ++cot)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = st1[cot][e], b2 = st2[cot][e];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b2 += __shfl_xor(b2, o, 64); }
+                st1[cot][e] = a; st2[cot][e] = b2;
+            }
+        __syncthreads();                             // every wave has left the main loop: the sample's tile is dead
+        float *red = reinterpret_cast<float *>(smem);    // [8 waves][2][64]
+        if (r == 0) {
+#pragma unroll
+            for (int cot = 0; cot < 4; ++cot) {
+                *reinterpret_cast<f32x4 *>(red + (wave * 2 + 0) * 64 + 16 * cot + 4 * q) = st1[cot];
+                *reinterpret_cast<f32x4 *>(red + (wave * 2 + 1) * 64 + 16 * cot + 4 * q) = st2[cot];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, ch = tid & 63;
+            float sacc = 0.f;
+#pragma unroll
+            for (int wv_ = 0; wv_ < 8; ++wv_) sacc += red[(wv_ * 2 + which) * 64 + ch];      // wave order: deterministic
+            partial[((size_t)blockIdx.x * 2 + which) * 64 + ch] = sacc;
+        }
+    }
 }
 
 
@@ -839,5 +879,26 @@ VV_EXPORT int vv_convT3d_k4s2_whole_fwd(const void *x, const void *w_skip, const
         case VV_ACT_LRELU: launch(std::integral_constant<int, VV_ACT_LRELU>{}); break;
         default: launch(std::integral_constant<int, VV_ACT_NONE>{}); break;
     }
+    return vv_launch_status();
+}
+
+// The training step's forward form: raw output (no folded BN, no activation: BatchNorm with batch statistics follows) + the
+// per-workgroup column sums of that output for vv_bn_finalize_stats.
+VV_EXPORT int vv_convT3d_k4s2_whole_stats_blocks(int batch) { return batch > 0 ? batch : 0; }
+
+VV_EXPORT int vv_convT3d_k4s2_whole_stats_fwd(const void *x, const void *w_skip, void *y, float *stats_partial, size_t stats_bytes, int batch,
+                                              int side, int cin, int cout, int dtype, void *stream) {
+    if (!x || !w_skip || !y || !stats_partial) return VV_ERR_NULL;
+    if (!vv_convT3d_k4s2_whole_supported(side, cin, cout, dtype) || batch <= 0) return VV_ERR_SHAPE;
+    if (!vv_aligned16(x) || !vv_aligned16(w_skip) || !vv_aligned16(y) || !vv_aligned16(stats_partial)) return VV_ERR_ALIGN;
+    if (stats_bytes < (size_t)batch * 2 * 64 * sizeof(float)) return VV_ERR_WORKSPACE;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ctw16_kernel<VV_ACT_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS);
+        return true;
+    }();
+    (void)attr;
+    VV_LAUNCH((ctw16_kernel<VV_ACT_NONE, true>), dim3((unsigned)batch), dim3(512), CW_LDS, reinterpret_cast<hipStream_t>(stream),
+              reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(w_skip), nullptr, nullptr, reinterpret_cast<__bf16 *>(y), 8,
+              stats_partial);
     return vv_launch_status();
 }

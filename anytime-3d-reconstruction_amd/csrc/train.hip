@@ -925,6 +925,18 @@ VV_EXPORT int vv_bn_train_stats(const void *x, long rows, int channels, const fl
     return vv_launch_status();
 }
 
+// The second half of vv_bn_train_stats for a producer that left the per-block column sums itself (vv_convT3d_k4s2_whole_stats_fwd):
+// partial[(block * 2 + {0: sum, 1: sum of squares}) * channels + channel] over `nblocks` blocks that together cover `rows` rows.
+VV_EXPORT int vv_bn_finalize_stats(const float *partial, int nblocks, long rows, int channels, const float *gamma, const float *beta, float eps,
+                                   float momentum, float *mean, float *var, float *rstd, float *scale, float *shift, float *moving_mean,
+                                   float *moving_var, void *stream) {
+    if (!partial || !gamma || !beta || !mean || !var || !rstd || !scale || !shift) return VV_ERR_NULL;
+    if (nblocks <= 0 || rows <= 0 || channels <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(bn_stats_finalize_kernel, dim3((channels + BN_FC - 1) / BN_FC), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, nblocks,
+              rows, channels, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, moving_mean, moving_var);
+    return vv_launch_status();
+}
+
 VV_EXPORT int vv_bn_act_fwd(const void *x, const float *scale, const float *shift, void *y, long rows, int channels, int act,
                             int dtype, void *stream) {
     if (!x || !scale || !shift || !y) return VV_ERR_NULL;

@@ -100,6 +100,9 @@ SIGNATURES = {
     'vv_sampling': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'vv_bn_workspace_bytes': (_sz, [_l, _i]),
     'vv_bn_train_stats': (_i, [_vp, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'vv_bn_finalize_stats': (_i, [_vp, _i, _l, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'vv_convT3d_k4s2_whole_stats_blocks': (_i, [_i]),
+    'vv_convT3d_k4s2_whole_stats_fwd': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'vv_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     'vv_bn_act_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
     'vv_wgrad_workspace_bytes': (_sz, [_l, _i, _i]),

@@ -314,6 +314,17 @@ class Trainer:
         L.call('vv_bn_act_fwd', L.ptr(c), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(h), rows, ch, act, self._dt(c), _st())
         return h, bn
 
+    def _bn_fwd_from_partials(self, c, partial, nblocks, rows, ch, eng, prefix, act):
+        """_bn_fwd for a layer whose producer left the per-block column sums (vv_convT3d_k4s2_whole_stats_fwd): finalise + apply."""
+        bn = _BN(ch, self.dev)
+        p = eng.params
+        L.call('vv_bn_finalize_stats', L.ptr(partial), nblocks, rows, ch, L.ptr(p[prefix + '/gamma']), L.ptr(p[prefix + '/beta']), BN_EPS, BN_MOMENTUM,
+               L.ptr(bn.mean), L.ptr(bn.var), L.ptr(bn.rstd), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(p[prefix + '/moving_mean']),
+               L.ptr(p[prefix + '/moving_variance']), _st())
+        h = torch.empty_like(c)
+        L.call('vv_bn_act_fwd', L.ptr(c), L.ptr(bn.scale), L.ptr(bn.shift), L.ptr(h), rows, ch, act, self._dt(c), _st())
+        return h, bn
+
     def _bn_bwd(self, c, dh, bn, rows, gname, bname, act):
         dc = torch.empty_like(c)
         ws = self.ws.get(L.load().vv_bn_workspace_bytes(rows, bn.c))
@@ -595,11 +606,24 @@ class Trainer:
         h_d1, bn_d1 = self._bn_fwd(c_d1, B * S ** 3, fd[0], dec, 'bnT0', act)
         dc_, dh_, dbn = [c_d1], [h_d1], [bn_d1]
         side = S
+        lib = L.load()
         for i in range(1, len(fd) - 1):
-            c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i], packed=dec.packed['w%d' % i],
-                            packed_frag=dec.packed.get('wf%d' % i), packed_whole=dec.packed.get('ww%d' % i))
-            side *= 2
-            h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
+            ww = dec.packed.get('ww%d' % i)
+            if (ww is not None and not os.environ.get('VV_NO_STATS_FUSION') and not os.environ.get('VV_NO_WHOLE') and not os.environ.get('VV_NO_DIRECT')
+                    and lib.vv_convT3d_k4s2_whole_supported(side, fd[i - 1], fd[i], dt)):
+                # the widest decoder layer: its kernel leaves the column sums of its own output (no statistics sweep over 134 MB)
+                c = self._aempty(B, 2 * side, 2 * side, 2 * side, fd[i])
+                nblk = lib.vv_convT3d_k4s2_whole_stats_blocks(B)
+                part = self._empty(nblk * 2 * fd[i])
+                L.call('vv_convT3d_k4s2_whole_stats_fwd', L.ptr(dh_[-1]), L.ptr(ww), L.ptr(c), L.ptr(part), part.numel() * 4, B, side, fd[i - 1], fd[i],
+                       dt, st)
+                side *= 2
+                h, bn = self._bn_fwd_from_partials(c, part, nblk, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
+            else:
+                c = self._convT(dh_[-1], dec.params['convT%d/kernel' % i], B, side, fd[i - 1], fd[i], packed=dec.packed['w%d' % i],
+                                packed_frag=dec.packed.get('wf%d' % i), packed_whole=ww)
+                side *= 2
+                h, bn = self._bn_fwd(c, B * side ** 3, fd[i], dec, 'bnT%d' % i, act)
             dc_.append(c); dh_.append(h); dbn.append(bn)
         nd = len(fd) - 1
         w5 = dec.params['convT%d/kernel' % nd]

@@ -302,6 +302,17 @@ int vv_bn_train_stats(const void *x, long rows, int channels, const float *gamma
                       float momentum, float *mean, float *var, float *rstd, float *scale, float *shift,
                       float *moving_mean, float *moving_var, int dtype, void *workspace, size_t workspace_bytes,
                       void *stream);
+/* Batch statistics from per-block column sums a producer kernel left (round 4): the widest decoder layer's training-mode forward,
+ * vv_convT3d_k4s2_whole_stats_fwd (raw bf16 output + partial[(block * 2 + {sum, sum of squares}) * cout + channel], block = sample;
+ * vv_convT3d_k4s2_whole_stats_blocks(batch) blocks), and the finalisation of vv_bn_train_stats on such partials: the statistics
+ * sweep over the layer's output is not run.  Same results as vv_convT3d_k4s2_whole_fwd + vv_bn_train_stats up to the float32
+ * summation order of the column sums (finalised in double). */
+int vv_convT3d_k4s2_whole_stats_blocks(int batch);
+int vv_convT3d_k4s2_whole_stats_fwd(const void *x, const void *w_skip, void *y, float *stats_partial, size_t stats_bytes, int batch,
+                                    int side, int cin, int cout, int dtype, void *stream);
+int vv_bn_finalize_stats(const float *partial, int nblocks, long rows, int channels, const float *gamma, const float *beta, float eps,
+                         float momentum, float *mean, float *var, float *rstd, float *scale, float *shift, float *moving_mean,
+                         float *moving_var, void *stream);
 /* y = act(x*scale + shift) */
 int vv_bn_act_fwd(const void *x, const float *scale, const float *shift, void *y, long rows, int channels, int act,
                   int dtype, void *stream);

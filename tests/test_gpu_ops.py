@@ -171,6 +171,51 @@ def test_convT3d_k4s2_whole(L, B, act, ps, shape, monkeypatch):
         _check(y2, no.conv3d_transpose_same(x.astype(np.float64), w.astype(np.float64), 2), 'bf16', 'convT3d_k4s2_whole (no BN)')
 
 
+@pytest.mark.parametrize('B', [3, 64, 256])
+def test_convT3d_whole_stats_form(L, B):
+    """The training-mode forward of the widest decoder layer (round 4): the kernel that leaves the per-workgroup column sums of its own
+    output.  Output bit-identical to the plain raw form; the column sums are those of the stored bf16 values; finalised, they are the
+    batch statistics vv_bn_train_stats computes from the tensor (mean / variance / folded scale and shift / moving statistics)."""
+    g = torch.Generator(device=DEV).manual_seed(B)
+    cin, cout = 128, 64
+    x = torch.randn(B, 8, 8, 8, cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(4, 4, 4, cout, cin, device=DEV, generator=g) / (8 * cin) ** 0.5).contiguous()
+    wk = torch.empty(64 * cin * cout, dtype=torch.bfloat16, device=DEV)
+    L.call('vv_pack_convT_k4s2_skip', L.ptr(w), L.ptr(wk), cin, cout, _st())
+    lib = L.load()
+    y0 = torch.full((B, 16, 16, 16, cout), float('nan'), dtype=torch.bfloat16, device=DEV)
+    L.call('vv_convT3d_k4s2_whole_fwd', L.ptr(x), L.ptr(wk), None, None, L.ptr(y0), B, 8, cin, cout, 0, L.VV_BF16, _st())
+    nblk = lib.vv_convT3d_k4s2_whole_stats_blocks(B)
+    part = torch.full((nblk, 2, cout), float('nan'), dtype=torch.float32, device=DEV)
+    y1 = torch.full_like(y0, float('nan'))
+    L.call('vv_convT3d_k4s2_whole_stats_fwd', L.ptr(x), L.ptr(wk), L.ptr(y1), L.ptr(part), part.numel() * 4, B, 8, cin, cout, L.VV_BF16, _st())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    yf = y1.double().reshape(-1, cout)
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    R = yf.shape[0]
+    assert torch.allclose(s1, yf.sum(0), rtol=0, atol=2e-5 * float(yf.abs().sum(0).max()))
+    assert torch.allclose(s2, (yf * yf).sum(0), rtol=2e-5, atol=0)
+    # finalise: against vv_bn_train_stats on the tensor
+    gamma, beta = torch.rand(cout, device=DEV, generator=g) + 0.5, torch.randn(cout, device=DEV, generator=g)
+    outs = []
+    for form in (0, 1):
+        mean, var, rstd, scale, shift = (torch.empty(cout, device=DEV) for _ in range(5))
+        mm, mv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        if form == 0:
+            ws = torch.empty(max(lib.vv_bn_workspace_bytes(R, cout), 16), dtype=torch.uint8, device=DEV)
+            L.call('vv_bn_train_stats', L.ptr(y1), R, cout, L.ptr(gamma), L.ptr(beta), 1e-3, 0.99, L.ptr(mean), L.ptr(var), L.ptr(rstd), L.ptr(scale),
+                   L.ptr(shift), L.ptr(mm), L.ptr(mv), L.VV_BF16, L.ptr(ws), ws.numel(), _st())
+        else:
+            L.call('vv_bn_finalize_stats', L.ptr(part), nblk, R, cout, L.ptr(gamma), L.ptr(beta), 1e-3, 0.99, L.ptr(mean), L.ptr(var), L.ptr(rstd),
+                   L.ptr(scale), L.ptr(shift), L.ptr(mm), L.ptr(mv), _st())
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (mean, var, rstd, scale, shift, mm, mv)])
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), (a - b).abs().max()
+    assert lib.vv_convT3d_k4s2_whole_stats_fwd(L.ptr(x), L.ptr(wk), L.ptr(y1), L.ptr(part), 16, B, 8, cin, cout, L.VV_BF16, _st()) == -5
+
+
 # position-major split-K GEMM of the 4^3 <-> 2^3 layers (posgemm.hip): ragged batches, channel tails, several sample tiles
 @pytest.mark.parametrize('act', [1, 0])
 @pytest.mark.parametrize('B,cin,cout', [(5, 64, 64), (37, 256, 512), (256, 128, 136), (300, 64, 128)])
