@@ -182,6 +182,11 @@ __global__ void pack_conv_k4s1_full_kernel(const float *__restrict__ w, T *__res
 }
 
 // out[b][c] = max over positions p of x[b][p][c] (tf.reduce_max over the spatial axes, autoencoder3D.py:92-93)
+// tf.nn.sigmoid on the encoder output (autoencoder3D.py:97-99, final_activation 'sigmoid'); in place allowed
+__global__ void sigmoid_f32_kernel(const float *__restrict__ x, float *__restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
 __global__ void max_over_positions_kernel(const float *__restrict__ x, float *__restrict__ out, int batch, int npos, int channels) {
     const size_t total = (size_t)batch * channels;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -400,6 +405,13 @@ VV_EXPORT int vv_pack_conv_k4s1_full(const float *w_keras, void *packed, int sid
     if (cin <= 0 || cout <= 0 || side <= 0) return VV_ERR_SHAPE;
     const size_t s3 = (size_t)side * side * side;
     VV_PACK_DISPATCH(pack_conv_k4s1_full_kernel, s3 * cout * s3 * cin, side, cin, cout);
+}
+
+VV_EXPORT int vv_sigmoid_f32(const float *x, float *y, long n, void *stream) {
+    if (!x || !y) return VV_ERR_NULL;
+    if (n <= 0) return VV_ERR_SHAPE;
+    VV_LAUNCH(sigmoid_f32_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n);
+    return vv_launch_status();
 }
 
 VV_EXPORT int vv_max_over_positions(const float *x, float *out, int batch, int npos, int channels, void *stream) {

@@ -230,19 +230,21 @@ class EncoderEngine(_EngineBase):
         if any(int(k) != 4 for k in s['filter_size_list']) or [int(v) for v in s['strides_list']] != [2] * (n - 1) + [1]:
             raise NotImplementedError('encoder3D kernels cover filter size 4 with strides [2]*(n-1)+[1] '
                                       '(every config of the reference)')
-        if s['final_pool'] not in ('average', 'max'):
-            raise NotImplementedError("final_pool=%r: 'average' (every reference config) or 'max' (autoencoder3D.py:90-93)" % s['final_pool'])
+        if s['final_pool'] not in ('average', 'max', 'None', None):
+            raise NotImplementedError("final_pool=%r: 'average' (every reference config), 'max' or 'None' (autoencoder3D.py:90-95)" % s['final_pool'])
         self.pool_max = s['final_pool'] == 'max'
-        if s['final_activation'] not in (None, 'None', 'linear'):
+        self.pool_none = s['final_pool'] in ('None', None)      # no pooling: the model returns the last conv's [B,S,S,S,E] map
+        self.final_sigmoid = s['final_activation'] == 'sigmoid'  # tf.nn.sigmoid on the output (autoencoder3D.py:97-99)
+        if not self.final_sigmoid and s['final_activation'] not in (None, 'None', 'linear'):
             raise NotImplementedError('encoder final_activation %r' % s['final_activation'])
         if self.D >> (n - 1) < 1:
             raise ValueError('grid too small for %d stride-2 layers' % (n - 1))
         self.S = self.D >> (n - 1)      # side of the last feature map
         self.E = self.filters[-1]
-        if self.pool_max and (self.S ** 3 * self.E) * (self.S ** 3 * self.filters[-2]) > (1 << 28):
+        if (self.pool_max or self.pool_none) and (self.S ** 3 * self.E) * (self.S ** 3 * self.filters[-2]) > (1 << 28):
             # the max pool is not linear, so the last conv runs position by position as one dense panel [S^3 E][S^3 Cin]; that is 4 M
             # elements at the 32^3 geometry (S = 2) and 268 M at 64^3 (S = 4): no reference config asks for it there
-            raise NotImplementedError("final_pool='max' with a %d^3 last feature map" % self.S)
+            raise NotImplementedError("final_pool=%r with a %d^3 last feature map" % (s['final_pool'], self.S))
 
     def param_shapes(self):
         shp, cin = {}, 1
@@ -293,8 +295,8 @@ class EncoderEngine(_EngineBase):
                 L.call('vv_pack_conv_k4_skip', L.ptr(p['conv%d/kernel' % i]), L.ptr(ws), f[i - 1], f[i], st)
                 self.packed['ws%d' % i] = ws
         i = len(f) - 1
-        if self.pool_max:
-            # tf.reduce_max over the positions (autoencoder3D.py:92-93): the conv output itself is needed -> full panel [S^3 E][S^3 Cin]
+        if self.pool_max or self.pool_none:
+            # tf.reduce_max over the positions (autoencoder3D.py:92-93) / no pooling: the conv output itself is needed -> full panel [S^3 E][S^3 Cin]
             w = self._empty(self.S ** 3 * f[i], self.S ** 3 * f[i - 1])
             L.call('vv_pack_conv_k4s1_full', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), self.S, f[i - 1], f[i], self.dt, st)
             self.packed['w%d' % i] = w
@@ -372,7 +374,7 @@ class EncoderEngine(_EngineBase):
         i = len(f) - 1
         K = side ** 3 * f[i - 1]
         q = pk.get('q%d' % i, False)
-        if self.pool_max:
+        if self.pool_max or self.pool_none:
             if stop_before_tail:
                 raise L.VoxVaeError("stop_before_tail: the fused latent tail folds the MEAN pool into its weights")
             if hdt != self.dt:
@@ -382,12 +384,19 @@ class EncoderEngine(_EngineBase):
             full = self._empty(B, P, f[i], dtype=torch.float32)
             self._call('E%d' % (i + 1), 'vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), None, None, L.ptr(full), B, P * f[i], K, 0,
                        self.dt, L.VV_F32, L.ptr(ws), ws.numel(), st)
-            out = self._empty(B, f[i], dtype=torch.float32)
-            self._call('E%dp' % (i + 1), 'vv_max_over_positions', L.ptr(full), L.ptr(out), B, P, f[i], st)
+            if self.pool_none:
+                out = full.view(B, side, side, side, f[i])
+            else:
+                out = self._empty(B, f[i], dtype=torch.float32)
+                self._call('E%dp' % (i + 1), 'vv_max_over_positions', L.ptr(full), L.ptr(out), B, P, f[i], st)
+            if self.final_sigmoid:
+                self._call('E%ds' % (i + 1), 'vv_sigmoid_f32', L.ptr(out), L.ptr(out), out.numel(), st)
             return out
         if stop_before_tail:
             if q or hdt != self.dt:
                 raise L.VoxVaeError('stop_before_tail: the fused latent tail takes a %s activation' % self.tdt)
+            if self.final_sigmoid:
+                raise L.VoxVaeError("stop_before_tail: the fused latent tail has no sigmoid on the encoder output")
             return h
         if q and hdt != L.VV_FP8:
             h = self._as_fp8(h, 'E%dc' % (i + 1))
@@ -396,6 +405,8 @@ class EncoderEngine(_EngineBase):
         out = self._empty(B, f[i], dtype=torch.float32)
         self._call('E%d' % (i + 1), 'vv_dense_fwd', L.ptr(h), L.ptr(pk['w%d' % i]), L.ptr(pk.get('scale%d' % i)), None, L.ptr(out), B, f[i], K, 0,
                    ddt, L.VV_F32, L.ptr(ws), ws.numel(), st)
+        if self.final_sigmoid:
+            self._call('E%ds' % (i + 1), 'vv_sigmoid_f32', L.ptr(out), L.ptr(out), out.numel(), st)
         return out
 
 
@@ -607,7 +618,7 @@ def reparam_kl(enc_out, eps, latent, act_dtype, drop_mask=None, drop_scale=1.0, 
 
 def latent_tail_supported(enc, dec, variational):
     """True when encoder tail -> reparam/KL -> Dense -> first decoder layer can run as the two fused launches of latent_tail.hip."""
-    if getattr(enc, 'pool_max', False):
+    if getattr(enc, 'pool_max', False) or getattr(enc, 'pool_none', False) or getattr(enc, 'final_sigmoid', False):
         return False
     if enc.dt != L.VV_BF16 or enc.fp8 or dec.fp8 or dec.dt != L.VV_BF16 or os.environ.get('VV_NO_LATENT_TAIL'):
         return False

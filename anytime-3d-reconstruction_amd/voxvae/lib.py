@@ -36,6 +36,7 @@ SIGNATURES = {
     'vv_pack_conv_k4s1_meanpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'vv_pack_conv_k4s1_full': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'vv_max_over_positions': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'vv_sigmoid_f32': (_i, [_vp, _vp, _l, _vp]),
     'vv_pack_convT_k4s1_dense': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'vv_pack_dense': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'vv_fold_bn': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]),

@@ -214,6 +214,8 @@ class Trainer:
             raise ValueError('encoder and decoder engines must share one activation dtype')
         if dec.fp8 or (enc is not None and enc.fp8):
             raise ValueError("fit() runs in 'f32' or 'bf16'; 'fp8' is an inference mode (quantised weight images)")
+        if enc is not None and (getattr(enc, 'pool_none', False) or getattr(enc, 'final_sigmoid', False)):
+            raise NotImplementedError("fit() with final_pool='None' / an encoder final_activation: inference only (no reference config trains with them)")
         if enc is not None and getattr(enc, 'pool_max', False):
             raise NotImplementedError("fit() with final_pool='max': the training step folds the mean pool into the last conv's panel; "
                                       "no reference config trains with the max pool")
@@ -519,8 +521,8 @@ class Trainer:
         return stats, metrics, aux
 
     def _encoder_forward(self, x, B):
-        if getattr(self.enc, 'pool_max', False):
-            raise NotImplementedError("training-mode forward with final_pool='max'")
+        if getattr(self.enc, 'pool_max', False) or getattr(self.enc, 'pool_none', False) or getattr(self.enc, 'final_sigmoid', False):
+            raise NotImplementedError("training-mode forward with final_pool='max' / 'None' or an encoder final_activation")
         enc, st, dt = self.enc, _st(), self.dt
         D, fe, act = enc.D, enc.filters, enc.act
         # ---------------- encoder forward (raw conv -> batch stats -> BN + act)

@@ -58,6 +58,8 @@ int vv_pack_conv_k4s1_meanpool(const float *w_keras, void *packed, int side, int
  * panel gives the conv output [B][S^3][Cout], vv_max_over_positions the pooled [B][Cout]. */
 int vv_pack_conv_k4s1_full(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);
 int vv_max_over_positions(const float *x, float *out, int batch, int npos, int channels, void *stream);
+/* y = sigmoid(x), float32, n elements (in place allowed): encoder3D's final_activation 'sigmoid' (autoencoder3D.py:97-99). */
+int vv_sigmoid_f32(const float *x, float *y, long n, void *stream);
 /* First decoder Conv3DTranspose k4 s1 SAME on the S^3 x Cin seed (autoencoder3D.py:127-128, first loop
  * iteration) as one dense panel: packed [S^3*Cout][S^3*Cin], row (o,co), col (j,ci) = w[o - j + 1][co][ci]. */
 int vv_pack_convT_k4s1_dense(const float *w_keras, void *packed, int side, int cin, int cout, int dtype, void *stream);

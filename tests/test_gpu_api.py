@@ -904,6 +904,36 @@ def test_bit_packed_host_batches_give_the_float_batches_results():
         hostio._STATE['max_pooled_bytes'] = keep
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('pool,final_act', [('None', 'None'), ('average', 'sigmoid'), ('max', 'sigmoid'), ('None', 'sigmoid')])
+def test_encoder_builder_pool_none_and_sigmoid(dtype, pool, final_act):
+    """The builder-level options of encoder3D that no reference configuration uses (autoencoder3D.py:90-99): final_pool 'None' (the
+    model returns the last convolution's [B,S,S,S,E] map) and final_activation 'sigmoid' -- inference path, against the float64
+    definition (oracle/numpy_oracle.encoder3D_forward); fit() refuses them."""
+    import voxvae
+    from oracle import numpy_oracle as no
+    from voxvae import synthetic as syn
+    voxvae.set_default_dtype(dtype)
+    voxvae.set_default_device('cuda:0')
+    import src.net_core.autoencoder3D as ae
+    cfg = syn.make_config(32, 64, True)['encoder']
+    cfg = dict(cfg, final_pool=pool, final_activation=final_act)
+    ep = syn.make_encoder_params(cfg)
+    enc = ae.encoder3D(cfg)
+    enc.set_weights_dict(ep)
+    B = 4
+    x = syn.make_voxels(B, 32, seed=51)
+    got = np.array(enc(x))
+    ref = no.encoder3D_forward(cfg, {k: np.asarray(v, np.float64) for k, v in ep.items()}, x.astype(np.float64))
+    assert got.shape == ref.shape == ((B, 2, 2, 2, 128) if pool == 'None' else (B, 128))
+    tol = 2e-5 if dtype == 'f32' else 3e-2
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(1.0, np.abs(ref).max()))
+    if final_act == 'sigmoid':
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    with pytest.raises(NotImplementedError):
+        enc(x, training=True)
+
+
 @pytest.mark.parametrize('dtype,D', [('f32', 32), ('bf16', 32), ('f32', 16)])
 def test_encoder_final_pool_max(dtype, D):
     """final_pool = 'max' (reference autoencoder3D.py:92-93): tf.reduce_max is not linear, so the last conv runs position by
