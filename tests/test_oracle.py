@@ -56,6 +56,45 @@ def test_conv3d_transpose_same_three_statements(D, Ci, Co, s):
     np.testing.assert_allclose(co.conv3d_transpose_same(x, w, s), y_np, rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize('D,Ci,Co,s', [(8, 2, 3, 2), (6, 1, 2, 2), (4, 3, 2, 1), (7, 2, 2, 2)])
+def test_conv_and_transpose_against_scipy_correlate(D, Ci, Co, s):
+    """A fourth, independent statement (round 4): scipy.signal.correlate / convolve, an N-D routine that shares no code with numpy_oracle's
+    tap loops, the C restatement or torch's oneDNN path.  Conv3D SAME = 'valid' cross-correlation of the TF-padded input, strided by
+    slicing; Conv3DTranspose SAME = full convolution of the zero-stuffed input with the kernel, cropped by pad_before (the gradient-of-conv
+    definition TensorFlow documents)."""
+    from scipy import signal
+    rng = np.random.default_rng(D * 7 + Ci)
+    x = rng.standard_normal((2, D, D, D, Ci))
+    w = rng.standard_normal((4, 4, 4, Ci, Co))
+    out_n = -(-D // s)
+    pad_total = max((out_n - 1) * s + 4 - D, 0)
+    pb = pad_total // 2
+    xp = np.pad(x, ((0, 0),) + ((pb, pad_total - pb),) * 3 + ((0, 0),))
+    y = np.zeros((2, out_n, out_n, out_n, Co))
+    for b in range(2):
+        for co in range(Co):
+            acc = sum(signal.correlate(xp[b, ..., ci], w[..., ci, co], mode='valid') for ci in range(Ci))
+            y[b, ..., co] = acc[::s, ::s, ::s][:out_n, :out_n, :out_n]
+    np.testing.assert_allclose(no.conv3d_same(x, w, s), y, rtol=0, atol=1e-10)
+    # transposed: Keras kernel [k,k,k,Cout_T,Cin_T]; input z [2,n,n,n,Cin_T] -> [2,n*s,n*s,n*s,Cout_T]
+    n = out_n
+    z = rng.standard_normal((2, n, n, n, Co))
+    wt = rng.standard_normal((4, 4, 4, Ci, Co))                     # Cout_T = Ci, Cin_T = Co
+    N = n * s
+    pt = max((n - 1) * s + 4 - N, 0)
+    ptb = pt // 2
+    yt = np.zeros((2, N, N, N, Ci))
+    for b in range(2):
+        for co in range(Ci):
+            acc = 0.0
+            for ci in range(Co):
+                up = np.zeros(((n - 1) * s + 1,) * 3)
+                up[::s, ::s, ::s] = z[b, ..., ci]
+                acc = acc + signal.convolve(up, wt[..., co, ci], mode='full')
+            yt[b, ..., co] = acc[ptb:ptb + N, ptb:ptb + N, ptb:ptb + N]
+    np.testing.assert_allclose(no.conv3d_transpose_same(z, wt, s), yt, rtol=0, atol=1e-10)
+
+
 def test_transpose_is_adjoint_of_conv():
     """<conv(x), y> == <x, convT(y)> for the same kernel: the defining property of Conv3DTranspose."""
     rng = np.random.default_rng(3)
