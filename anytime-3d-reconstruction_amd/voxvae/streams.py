@@ -18,12 +18,17 @@ import torch
 
 
 class StreamedEvaluator:
-    def __init__(self, model_factory, streams=3, device=None, replicas=False):
+    def __init__(self, model_factory, streams=3, device=None, replicas=False, priorities=None):
+        """priorities: optional list of HIP stream priorities (0 = normal, -1 = high), one per stream (an experiment knob: a stream that
+        wins every arbitration keeps its producer -> consumer hand-offs adjacent on the device)."""
         if streams < 1:
             raise ValueError('streams must be >= 1')
         self.models = [model_factory() for _ in range(streams)] if replicas else [model_factory()] * streams
         self.device = torch.device(device) if device is not None else self.models[0]._device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)] if streams > 1 else [None]
+        pr = list(priorities) if priorities else [0] * streams
+        if len(pr) != streams:
+            raise ValueError('one priority per stream')
+        self.streams = [torch.cuda.Stream(device=self.device, priority=int(pr[i])) for i in range(streams)] if streams > 1 else [None]
         self._next = 0
         self._pack_event, self._pack_pending = None, set()
 

@@ -459,7 +459,8 @@ def main():
 
     from voxvae.streams import StreamedEvaluator
     nstreams = max(1, a.streams) if a.mode == 'eval' else 1
-    ev = StreamedEvaluator(build_model, streams=nstreams, device=dev)
+    prio = [int(v) for v in os.environ['VV_STREAM_PRIO'].split(',')] if os.environ.get('VV_STREAM_PRIO') else None      # experiment knob
+    ev = StreamedEvaluator(build_model, streams=nstreams, device=dev, priorities=prio)
     model = ev.models[0]
     xh = syn.make_voxels(a.batch, a.voxel, seed=1234 + rank)
     epsh = syn.make_eps(a.batch, a.latent, seed=7 + rank)
