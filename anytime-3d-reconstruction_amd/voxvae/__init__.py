@@ -8,7 +8,7 @@
 import os
 
 _DEFAULTS = {'dtype': os.environ.get('VOXVAE_DTYPE', 'f32'), 'device': os.environ.get('VOXVAE_DEVICE', 'cuda:0'),
-             'fp8_policy': os.environ.get('VV_FP8_POLICY', 'wide')}
+             'fp8_policy': os.environ.get('VV_FP8_POLICY', 'mid')}
 
 
 def set_default_dtype(dtype):
@@ -22,16 +22,19 @@ def set_default_dtype(dtype):
 def set_fp8_policy(policy):
     """Which MFMA layers run on e4m3fn operands in 'fp8' mode (engines built afterwards).
 
-    'wide' (default): the layers that have a direct fp8 kernel -- the widest encoder and decoder layer (E2 / D4 at 32^3:
-           62 % of the path's FLOPs and nearly all of the time fp8 saves).  Measured at the TRAINED operating points
-           (tests/test_gpu_trained.py; 256 samples each): mean IoU within 5.0e-4 (32^3) / 4.3e-4 (64^3, BASELINE config 5's geometry)
-           of the float32 oracle -- north_star's bar is 1e-3.  The weight images are rounded with error diffusion over the taps an
-           output sums (engine.quant_fp8), which removes the weight rounding's share of that cost.
-    'all':  every layer whose Cin is a multiple of 128 (and E2 through tap-pair rows), as in rounds 1-2.  Fastest, but each
-           fp8 layer adds ~1-3 % of noise to its pre-activations (3 mantissa bits on both operands), and at a trained operating
-           point the sum costs 1.44e-3 (32^3) / 1.23e-3 (64^3) of mean IoU -- beyond the bar; the layers between E3 and D3 also
-           gain little time."""
-    if policy not in ('wide', 'all'):
+    Measured at the TRAINED operating points (256 samples each, profiles/r04_fp8_policy_mid_{32,64}.jsonl; north_star's bar: mean IoU within
+    1e-3 of the float32 oracle); ms = one 256-batch at 32^3 / one 64-sample shard at 64^3, one stream:
+
+      policy   fp8 layers                          32^3: IoU delta, ms      64^3 (BASELINE config 5): IoU delta, ms
+      'wide'   E2, D4 (the direct fp8 kernels)     5.0e-4   0.439           4.3e-4   0.934
+      'mid'    E2, E3, D3, D4   (DEFAULT)          5.8e-4   0.419           6.5e-4   0.820
+      'most'   everything but the encoder tail     1.10e-3  0.409  (over)   7.4e-4   0.747   (inside, 3 standard errors reach the bar)
+      'all'    every eligible layer                1.44e-3  0.410  (over)   1.23e-3  0.745   (over)
+
+    'mid' is the widest policy that is inside the bar at BOTH points with three standard errors to spare.  The weight images are rounded
+    with error diffusion over the taps an output sums (engine.quant_fp8), which removes the weight rounding's share of the cost; what is
+    left is the 3-bit mantissa of the activations, and the encoder tail's share (+4.9e-4 at 64^3) is systematic: it moves z."""
+    if policy not in ('wide', 'mid', 'most', 'all'):
         raise ValueError(policy)
     _DEFAULTS['fp8_policy'] = policy
 

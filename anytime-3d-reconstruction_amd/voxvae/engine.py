@@ -145,7 +145,7 @@ class _EngineBase:
         if self.fp8:
             self.dt = L.VV_BF16
             from . import fp8_policy
-            self.fp8_policy = fp8_policy()        # 'wide': only the layers with a direct fp8 kernel; 'all': every eligible layer
+            self.fp8_policy = fp8_policy()        # 'wide': only the layers with a direct fp8 kernel; 'mid' / 'most' / 'all': voxvae.set_fp8_policy
         self.tdt = _tdtype(self.dt)
         self.device = torch.device(device)
         self.params = {}          # name -> float32 CUDA tensor, Keras layout (the trainable/master copy)
@@ -156,6 +156,22 @@ class _EngineBase:
         self.act = L.ACT[structure['activation']]
         self.timer = None         # LayerTimer or None
         self.tag = ''
+
+    def _fp8_off(self):
+        """Layers kept on bf16 operands in 'fp8' mode: the VV_FP8_OFF override plus what the policy excludes.  'mid' and 'most' are policy
+        'all' minus a set: 'mid' keeps fp8 on the two widest stride-2 layers of each side (E2, E3 / D3, D4 of the five-layer models),
+        'most' only takes the encoder tail back (the layer whose error moves the whole latent)."""
+        off = set(fp8_layers_off())
+        pol, n = getattr(self, 'fp8_policy', 'wide'), len(self.filters)
+        enc = isinstance(self, EncoderEngine)
+        if pol in ('mid', 'most') and enc:
+            off.add('E%d' % n)
+        if pol == 'mid':
+            if enc:
+                off |= set('E%d' % (i + 1) for i in range(3, n - 1))
+            else:
+                off |= set('D%d' % (i + 1) for i in range(1, n - 3))
+        return off
 
     def _call(self, layer, fn, *args):
         t = self.timer
@@ -265,7 +281,7 @@ class EncoderEngine(_EngineBase):
         for i in range(1, len(f) - 1):
             # Cin 64 (the second layer) has an fp8 form too (tap-pair rows); VV_FP8_E2=0 keeps it on the bf16 direct kernel
             q = self.fp8 and (f[i - 1] % 128 == 0 or (f[i - 1] == 64 and os.environ.get('VV_FP8_E2', '1') != '0')) \
-                and ('E%d' % (i + 1)) not in fp8_layers_off()
+                and ('E%d' % (i + 1)) not in self._fp8_off()
             if q and self.fp8_policy == 'wide':
                 q = bool(L.load().vv_conv3d_k4s2_direct_fp8_supported(self.D >> i, f[i - 1], f[i])) and os.environ.get('VV_FP8_E2', '1') != 'igemm'
             wk = p['conv%d/kernel' % i]
@@ -301,7 +317,7 @@ class EncoderEngine(_EngineBase):
             L.call('vv_pack_conv_k4s1_full', L.ptr(p['conv%d/kernel' % i]), L.ptr(w), self.S, f[i - 1], f[i], self.dt, st)
             self.packed['w%d' % i] = w
             return
-        q = self.fp8 and self.fp8_policy == 'all' and (self.S ** 3 * f[i - 1]) % 128 == 0 and ('E%d' % (i + 1)) not in fp8_layers_off()
+        q = self.fp8 and self.fp8_policy != 'wide' and (self.S ** 3 * f[i - 1]) % 128 == 0 and ('E%d' % (i + 1)) not in self._fp8_off()
         wk = p['conv%d/kernel' % i]
         if q:
             wk, qs = self._quant_fp8(wk, 4)
@@ -461,7 +477,7 @@ class DecoderEngine(_EngineBase):
         for i in range(1, len(f) - 1):
             side_i = self.S << (i - 1)
             direct = not os.environ.get('VV_NO_DIRECT') and bool(L.load().vv_convT3d_k4s2_direct_supported(side_i, f[i - 1], f[i], self.dt))
-            q = self.fp8 and f[i - 1] % 128 == 0 and ('D%d' % (i + 1)) not in fp8_layers_off()
+            q = self.fp8 and f[i - 1] % 128 == 0 and ('D%d' % (i + 1)) not in self._fp8_off()
             mode = os.environ.get('VV_FP8_LAST', 'direct')
             direct8 = q and direct and mode not in ('0', 'igemm') and bool(L.load().vv_convT3d_k4s2_direct_fp8_supported(side_i, f[i - 1], f[i]))
             if q and self.fp8_policy == 'wide' and not direct8:

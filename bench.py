@@ -56,9 +56,9 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'])
-    ap.add_argument('--fp8-policy', default='wide', choices=['wide', 'all'],
-                    help="--dtype fp8: 'wide' = fp8 operands on the layers with a direct fp8 kernel (meets the IoU bar at the trained operating "
-                         "point), 'all' = every eligible layer (rounds 1-2; 1.7e-3 of IoU at the trained operating point)")
+    ap.add_argument('--fp8-policy', default='mid', choices=['wide', 'mid', 'most', 'all'],
+                    help="--dtype fp8: 'mid' (default) = E2, E3, D3, D4 on fp8 operands, 'wide' = only the two layers with a direct fp8 kernel, 'most' = all but the encoder tail (these meet the IoU bar at the trained operating "
+                         "points, 'most' at 64^3 only), 'all' = every eligible layer (rounds 1-2; 1.2-1.4e-3 of IoU at the trained operating points)")
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--voxel', type=int, default=32)
     ap.add_argument('--latent', type=int, default=64)

@@ -25,10 +25,13 @@ if what == 'bench':
             ('bf16_b256_bench_unprofiled', '`--steps 400 --warmup 50`', 'reconstructions/s'),
             ('ab_unfused_tail_bf16_b256_bench', '`VV_NO_POS_TAIL=1`, `--steps 400 --warmup 50` (round-3 chain, same box)', 'reconstructions/s'),
             ('ab_fused_tail_bf16_b256_bench', 'the same with the fused tail', 'reconstructions/s'),
-            ('fp8_wide_b256_bench', '`--dtype fp8` (policy `wide`)', 'reconstructions/s'),
+            ('fp8_mid_b256_bench', '`--dtype fp8` (default policy `mid`: E2, E3, D3, D4 on e4m3fn)', 'reconstructions/s'),
+            ('fp8_wide_b256_bench', '`--dtype fp8 --fp8-policy wide` (E2, D4)', 'reconstructions/s'),
             ('fp8_all_b256_bench', '`--dtype fp8 --fp8-policy all` (opt-in, over the IoU bar)', 'reconstructions/s'),
             ('bf16_d64_b64_bench', '`--voxel 64 --batch 64` (config 5\'s per-GPU shard, bf16)', 'reconstructions/s'),
-            ('fp8_wide_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8` (config 5)', 'reconstructions/s'),
+            ('fp8_mid_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8` (config 5, default policy `mid`)', 'reconstructions/s'),
+            ('fp8_wide_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8 --fp8-policy wide`', 'reconstructions/s'),
+            ('fp8_most_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8 --fp8-policy most` (everything but the encoder tail)', 'reconstructions/s'),
             ('fp8_all_d64_b64_bench', '`--voxel 64 --batch 64 --dtype fp8 --fp8-policy all`', 'reconstructions/s'),
             ('train_bf16_b256_bench_unprofiled', '`--mode train --steps 100 --warmup 20` (config 4\'s per-rank shape)', 'samples/s'),
             ('launcher_n1_eval', '`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (RCCL group of one rank)', 'reconstructions/s'),

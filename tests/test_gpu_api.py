@@ -84,16 +84,26 @@ def test_fp8_inference_mode_api():
     operands (per-channel weight scales), the two-pass missing-modality evaluation included; fit() refuses (inference
     mode); switching the default back leaves other models untouched."""
     import voxvae
-    # default policy 'wide': only the layers with a direct fp8 kernel (E2 and D4 at 32^3) run fp8 operands
-    gw, _, mw, dw = _model('vae_d32_l64_b2', 'fp8')
-    assert voxvae.fp8_policy() == 'wide' and mw._enc_eng.fp8
-    mw.getEval(inputs=(dw['x'], dw['x'], dw['oh']), category_vectors=dw['cats'], missing_prob=0.0, _eps=dw['eps'])
-    assert [k for k in mw._enc_eng.packed if k.startswith('q')] == ['q1'] and [k for k in mw._dec_eng.packed if k.startswith('q')] == ['q3']
+    # default policy 'mid' (round 4): the two widest stride-2 layers of each side (E2, E3 / D3, D4) run fp8 operands; 'wide': only the
+    # layers with a direct fp8 kernel (E2, D4); 'most': everything but the encoder tail
+    assert voxvae.fp8_policy() == 'mid'
+    for pol, eq, dq in (('mid', ['q1', 'q2'], ['q2', 'q3']), ('wide', ['q1'], ['q3']), ('most', ['q1', 'q2', 'q3'], ['q1', 'q2', 'q3'])):
+        voxvae.set_fp8_policy(pol)
+        try:
+            gw, _, mw, dw = _model('vae_d32_l64_b2', 'fp8')
+        finally:
+            voxvae.set_fp8_policy('mid')
+        assert mw._enc_eng.fp8
+        mw.getEval(inputs=(dw['x'], dw['x'], dw['oh']), category_vectors=dw['cats'], missing_prob=0.0, _eps=dw['eps'])
+        assert sorted(k for k in mw._enc_eng.packed if k.startswith('q')) == eq, (pol, sorted(mw._enc_eng.packed))
+        assert sorted(k for k in mw._dec_eng.packed if k.startswith('q')) == dq, (pol, sorted(mw._dec_eng.packed))
+    with pytest.raises(ValueError):
+        voxvae.set_fp8_policy('everything')
     voxvae.set_fp8_policy('all')
     try:
         g, _, m8, d = _model('vae_d32_l64_b2', 'fp8')
     finally:
-        voxvae.set_fp8_policy('wide')
+        voxvae.set_fp8_policy('mid')
     assert m8._enc_eng.fp8 and m8._dec_eng.fp8
     x = d['x']
     out = m8.getEval(inputs=(x, x, d['oh']), category_vectors=d['cats'], missing_prob=0.5, _eps=d['eps'], _mask=d['mask'], _eps2=d['eps2'])
@@ -107,12 +117,12 @@ def test_fp8_inference_mode_api():
     with pytest.raises(ValueError):
         m8.fit((x, x))
     # the AE class (encoder output = latent, no sampling) and the 64^3 / latent-16 geometry run the same fp8 layers
-    for name, pol in (('ae_d32_l64_b2', 'all'), ('vae_d64_l16_b1', 'all'), ('vae_d64_l16_b1', 'wide')):
+    for name, pol in (('ae_d32_l64_b2', 'all'), ('vae_d64_l16_b1', 'all'), ('vae_d64_l16_b1', 'wide'), ('vae_d64_l16_b1', 'mid')):
         voxvae.set_fp8_policy(pol)
         try:
             g2, _, m2, d2 = _model(name, 'fp8')
         finally:
-            voxvae.set_fp8_policy('wide')
+            voxvae.set_fp8_policy('mid')
         out2 = m2.getEval(inputs=(d2['x'], d2['x'], d2['oh']), category_vectors=d2['cats'], missing_prob=0.5, _eps=d2['eps'], _mask=d2['mask'],
                           _eps2=d2['eps2'])
         sc2 = np.array([float(v) for v in out2[1:5]] + [float(v) for v in out2[6:10]])

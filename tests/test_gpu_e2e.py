@@ -108,7 +108,7 @@ def test_d64_vae_config_against_c_oracle(dtname, B, monkeypatch):
     from oracle import c_oracle as co
     from voxvae import synthetic as syn
     import voxvae
-    if dtname.startswith('fp8/all'):            # every eligible layer on fp8 operands (default policy 'wide': the direct-kernel layers)
+    if dtname.startswith('fp8/all'):            # every eligible layer on fp8 operands (default policy 'mid': the two widest stride-2 layers of each side)
         monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
     if dtname.endswith('+d5'):                  # opt-in: e4m3fn hand-over into the last layer as well
         monkeypatch.setenv('VV_FP8_D5', '1')

@@ -92,20 +92,20 @@ def test_f32_logits_occupancy_and_saturated_bce_on_trained_weights(trained):
     np.testing.assert_allclose(kl, ref['kl'], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8/all'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8/wide', 'fp8/all'])
 def test_reduced_precision_iou_on_trained_weights(trained, dtype, monkeypatch):
-    """bf16 and the default fp8 policy ('wide': the direct-kernel layers E2 / D4) meet north_star's bar at the trained operating
-    point: mean IoU within 1e-3 of the oracle.  Per-sample: bf16 within 5e-3; fp8 within 1e-2 (3 mantissa bits on both operands of
-    62 % of the FLOPs; measured 5.0e-4 with the error-diffused weight images of round 4, 7.1e-4 before).  'fp8/all' (every eligible
+    """bf16 and the default fp8 policy ('mid' since round 4: E2, E3 / D3, D4 on e4m3fn operands; measured 5.8e-4) meet north_star's bar at
+    the trained operating point: mean IoU within 1e-3 of the oracle; so does 'wide' (the direct-kernel layers E2 / D4: 5.0e-4 with the
+    error-diffused weight images of round 4, 7.1e-4 before).  Per-sample: bf16 within 5e-3; fp8 within 1e-2.  'fp8/all' (every eligible
     layer, rounds 1-2's mode) does NOT meet the 1e-3 bar here -- measured 1.44e-3 (1.7e-3 before round 4), always a LOSS of IoU: each
     fp8 layer adds 1-3 % of noise to its pre-activations and a fitted model sits at an optimum -- it is gated at 2e-3 so that the
     finding stays visible and bounded."""
     import voxvae
     t = trained
     ref = t['ref']
-    if dtype == 'fp8/all':
-        monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
-    mean_gate, sample_gate = {'bf16': (1e-3, 5e-3), 'fp8': (1e-3, 1e-2), 'fp8/all': (2e-3, 2e-2)}[dtype]
+    if '/' in dtype:
+        monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', dtype.split('/')[1])
+    mean_gate, sample_gate = {'bf16': (1e-3, 5e-3), 'fp8': (1e-3, 1e-2), 'fp8/wide': (1e-3, 1e-2), 'fp8/all': (2e-3, 2e-2)}[dtype]
     probs, logits, stats, stats2, kl = _run(_model(t, dtype.split('/')[0]), t)
     for s in (stats, stats2):
         iou = s[:, 1] / np.maximum(s[:, 1] + s[:, 2] + s[:, 3], 1)
@@ -184,20 +184,21 @@ def trained64():
     return dict(cfg=cfg, ep=ep, dp=dp, x=x, eps=eps, ref=ref, iou=iou, info=info)
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8/all'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp8', 'fp8/wide', 'fp8/most', 'fp8/all'])
 def test_config5_geometry_iou_on_trained_weights(trained64, dtype, monkeypatch):
     """Config 5's arithmetic at ITS geometry, at a trained operating point, 256 samples (standard error of the mean ~4e-5).
-    bf16 and the DEFAULT fp8 policy ('wide': e4m3fn operands on the two direct-kernel layers, weights rounded with error diffusion over
-    the taps an output sums -- engine.quant_fp8) meet north_star's 1e-3 with the gate AT 1e-3.  The per-layer study behind it
+    bf16, the DEFAULT fp8 policy ('mid' since round 4: e4m3fn operands on E2, E3, D3, D4; weights rounded with error diffusion over the taps
+    an output sums -- engine.quant_fp8), 'wide' (E2, D4) and 'most' (everything but the encoder tail) meet north_star's 1e-3 with the gate AT 1e-3.  The per-layer study behind it
     (profiles/microbench/fp8_schemes.py, profiles/r04_fp8_schemes_64.json): E2 alone 4.8e-4, D4 alone 2.7e-4, both 7.4e-4 with
     independently rounded weights; the weight rounding's share disappears with the diffusion; per-32-channel E8M0 activation scales
     change nothing (4.71e-4 against 4.75e-4 simulated: the error is the 3-bit mantissa of the LARGE values, not subnormals).  The
     all-layers policy stays opt-in and over the bar; it is gated at what it measures so that the finding stays visible and bounded."""
     import voxvae
     t = trained64
-    if dtype == 'fp8/all':
-        monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', 'all')
-    gate = {'bf16': 1e-3, 'fp8': 1e-3, 'fp8/all': 2e-3}[dtype]          # measured (round 4): 2.5e-5 / 4.3e-4 / 1.23e-3
+    if '/' in dtype:
+        monkeypatch.setitem(voxvae._DEFAULTS, 'fp8_policy', dtype.split('/')[1])
+    # measured (round 4, profiles/r04_fp8_policy_mid_64.jsonl): bf16 2.5e-5; 'mid' (the default) 6.5e-4; 'wide' 4.3e-4; 'most' 7.4e-4; 'all' 1.23e-3
+    gate = {'bf16': 1e-3, 'fp8': 1e-3, 'fp8/wide': 1e-3, 'fp8/most': 1e-3, 'fp8/all': 2e-3}[dtype]
     m = _model(t, dtype.split('/')[0])
     x, eps = torch.from_numpy(t['x']).to(DEV), torch.from_numpy(t['eps']).to(DEV)
     ious = []
