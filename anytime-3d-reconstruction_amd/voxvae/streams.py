@@ -123,11 +123,12 @@ class HostPipeline:
     def submit(self, inputs, category_vectors, missing_prob=0.0, **kw):
         m = self.model
         cur = torch.cuda.current_stream(self.device)
-        if m._enc_eng._dirty or m._dec_eng._dirty or not m._enc_eng._folded or not m._dec_eng._folded:
+        engines = [e for e in (getattr(m, '_enc_eng', None), getattr(m, '_dec_eng', None)) if e is not None]   # (the image -> 3D model has no voxel encoder)
+        if any(e._dirty or not e._folded for e in engines):
             for s in self.streams:                  # weight images are shared by the streams: repack with nothing in flight
                 cur.wait_stream(s)
-            m._enc_eng.ensure_packed()
-            m._dec_eng.ensure_packed()
+            for e in engines:
+                e.ensure_packed()
             for s in self.streams:
                 s.wait_stream(cur)
         s = self.streams[self._next]
