@@ -73,7 +73,8 @@ __device__ __forceinline__ void ldp(const float *p, int c, float (&o)[V]) {     
 }
 template <typename T>
 __device__ __forceinline__ float bn_act_grad(float u, int act) {                  // act'(u)
-    if (act == VV_ACT_ELU) return u > 0.f ? 1.f : (sizeof(T) == 4 ? expf(fminf(u, 0.f)) : __expf(fminf(u, 0.f)));
+    // ELU'(u) = 1 for u > 0, exp(u) otherwise = exp(min(u, 0)) for every u (exp(0) is exactly 1): no compare + select per element
+    if (act == VV_ACT_ELU) return sizeof(T) == 4 ? expf(fminf(u, 0.f)) : __expf(fminf(u, 0.f));
     if (act == VV_ACT_RELU) return u > 0.f ? 1.f : 0.f;
     if (act == VV_ACT_LRELU) return u > 0.f ? 1.f : 0.3f;
     return 1.f;
