@@ -59,7 +59,7 @@ if what == 'bench':
 
 if what == 'train':
     rows = list(csv.DictReader(open(os.path.join(HERE, rnd + '_train_bf16_b256_kernel_stats.csv'))))
-    steps = 25.0
+    steps = float(sum(int(r['Calls']) for r in rows if 'adam_multi_kernel' in r['Name']) or 25)      # one Adam launch per step
     groups = [('forward + data-gradient convolutions', ('conv_direct', 'ctw16', 'sd_kernel', 'pg_kernel', 'pg_reduce', 'first_conv', 'igemm', 'final_bce')),
               ('weight gradients', ('wgrad',)),
               ('BatchNorm: batch statistics (reduce + finalize)', ('bn_reduce_kernel<0', 'bn_stats_finalize')),
@@ -69,7 +69,7 @@ if what == 'train':
               ('weight packs (per step: the weights change)', ('pack', 'fold_bn')),]
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     used = set()
-    print('| share of the step (`%s_train_bf16_b256_kernel_stats.csv`, rocprofv3, 25 steps) | ms / step | %% of GPU time | launches / step |' % rnd)
+    print('| share of the step (`%s_train_bf16_b256_kernel_stats.csv`, rocprofv3, %d steps) | ms / step | %% of GPU time | launches / step |' % (rnd, steps))
     print('|---|---|---|---|')
     for name, subs in groups:
         sel = [r for r in rows if any(s_ in r['Name'] for s_ in subs) and r['Name'] not in used]
