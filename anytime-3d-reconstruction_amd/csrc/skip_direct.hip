@@ -76,10 +76,10 @@ __global__ void sd_pack_conv_kernel(const float *__restrict__ w, __bf16 *__restr
 // The same image through a 64 x 64 LDS tile (cout % 64 == 0): block (t * NC + c, n block) reads 64 k-rows x 64 n with 16-byte loads
 // along n and writes 64 n-rows of 64 consecutive k (128 B) -- both sides coalesced.  The element-wise form above reads with a
 // stride of cout floats (8x the bytes past L2) and took 30 us on the 8 M-element layer; the training step packs per use.
-__global__ __launch_bounds__(256) void sd_pack_conv_tiled_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+__device__ __forceinline__ void sd_pack_conv_tiled_body(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout, int kb, int nb) {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
-    const int kb = blockIdx.x, n0 = blockIdx.y * 64;             // kb = t * NC + c: Keras rows kb * 64 .. + 63 (row = t * cin + c * 64 + k)
+    const int n0 = nb * 64;                                      // kb = t * NC + c: Keras rows kb * 64 .. + 63 (row = t * cin + c * 64 + k)
     const int c4 = tid & 15, r = tid >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -100,12 +100,35 @@ __global__ __launch_bounds__(256) void sd_pack_conv_tiled_kernel(const float *__
     }
 }
 
+__global__ __launch_bounds__(256) void sd_pack_conv_tiled_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    sd_pack_conv_tiled_body(w, out, cin, cout, blockIdx.x, blockIdx.y);
+}
+
+// Several weight tensors in ONE launch (the training step packs nine such images per step, each a 5-8 us launch of its own): the job table
+// travels in the kernel arguments, a block finds its job by the running block count.
+constexpr int SD_MAXJOBS = 8;
+struct SdPackJobs {
+    const float *w[SD_MAXJOBS];
+    __bf16 *out[SD_MAXJOBS];
+    int cin[SD_MAXJOBS], cout[SD_MAXJOBS];
+    int first[SD_MAXJOBS + 1];             // first block of job j; first[njobs] = grid size
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void sd_pack_conv_tiled_multi_kernel(const SdPackJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && (int)blockIdx.x >= t.first[j + 1]) ++j;
+    const int lb = (int)blockIdx.x - t.first[j];
+    const int nkb = 64 * (t.cin[j] / 64);
+    sd_pack_conv_tiled_body(t.w[j], t.out[j], t.cin[j], t.cout[j], lb % nkb, lb / nkb);
+}
+
 // out[((((p*8 + a)*NC + c)*cout + n)*64 + k] = w[(t(p,a)*cout + n)*cin + c*64 + k],  t = 1 - p + 2a per axis
 // (Keras Conv3DTranspose [kd,kh,kw,Cout,Cin]); 8 consecutive k per thread: two 16-byte reads, one 16-byte write
-__global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+__device__ __forceinline__ void sd_pack_convT_body(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout, long bid, long nblk) {
     const int NC = cin / 64;
     const long total8 = (long)8 * cin * cout;
-    for (long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8; i8 += (long)gridDim.x * blockDim.x) {
+    for (long i8 = bid * blockDim.x + threadIdx.x; i8 < total8; i8 += nblk * blockDim.x) {
         const int k = (int)(i8 & 7) * 8;
         long r = i8 >> 3;
         const int n = (int)(r % cout); r /= cout;
@@ -122,6 +145,16 @@ __global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__rest
         for (int u = 0; u < 4; ++u) { o[u] = static_cast<__bf16>(v0[u]); o[4 + u] = static_cast<__bf16>(v1[u]); }
         *reinterpret_cast<bf16x8 *>(out + i8 * 8) = o;
     }
+}
+
+__global__ void sd_pack_convT_kernel(const float *__restrict__ w, __bf16 *__restrict__ out, int cin, int cout) {
+    sd_pack_convT_body(w, out, cin, cout, blockIdx.x, gridDim.x);
+}
+
+__global__ void sd_pack_convT_multi_kernel(const SdPackJobs t) {
+    int j = 0;
+    while (j + 1 < t.njobs && (int)blockIdx.x >= t.first[j + 1]) ++j;
+    sd_pack_convT_body(t.w[j], t.out[j], t.cin[j], t.cout[j], (int)blockIdx.x - t.first[j], t.first[j + 1] - t.first[j]);
 }
 
 #define SD_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
@@ -649,6 +682,46 @@ VV_EXPORT int vv_pack_convT_k4s2_skip(const float *w_keras, void *packed, int ci
     VV_LAUNCH(sd_pack_convT_kernel, dim3(sd_grid_1d((long)8 * cin * cout)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w_keras,
               reinterpret_cast<__bf16 *>(packed), cin, cout);
     return vv_launch_status();
+}
+
+// kinds[j]: 0 = vv_pack_conv_k4_skip, 1 = vv_pack_convT_k4s2_skip of (w_keras[j], cin[j], cout[j]) into packed[j]; one launch per kind and
+// per 8 jobs.  Same images, bit for bit, as the single calls.
+VV_EXPORT int vv_pack_skip_images(const int *kinds, const float *const *w_keras, void *const *packed, const int *cin, const int *cout, int njobs,
+                                  void *stream) {
+    if (!kinds || !w_keras || !packed || !cin || !cout) return VV_ERR_NULL;
+    if (njobs <= 0) return VV_ERR_SHAPE;
+    for (int j = 0; j < njobs; ++j) {
+        if (!w_keras[j] || !packed[j]) return VV_ERR_NULL;
+        if ((kinds[j] != 0 && kinds[j] != 1) || cin[j] <= 0 || cout[j] <= 0 || cin[j] % 64 || (kinds[j] == 0 && cout[j] % 64)) return VV_ERR_SHAPE;
+        if (!vv_aligned16(w_keras[j]) || !vv_aligned16(packed[j])) return VV_ERR_ALIGN;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int kind = 0; kind < 2; ++kind) {
+        SdPackJobs t;
+        t.njobs = 0;
+        t.first[0] = 0;
+        int rc_all = VV_OK;
+        auto flush = [&]() {
+            if (t.njobs == 0) return;
+            if (kind == 0) VV_LAUNCH(sd_pack_conv_tiled_multi_kernel, dim3(t.first[t.njobs]), dim3(256), 0, st, t);
+            else VV_LAUNCH(sd_pack_convT_multi_kernel, dim3(t.first[t.njobs]), dim3(256), 0, st, t);
+            const int rc = vv_launch_status();
+            if (rc != VV_OK) rc_all = rc;
+            t.njobs = 0;
+        };
+        for (int j = 0; j < njobs; ++j) {
+            if (kinds[j] != kind) continue;
+            const int n = t.njobs;
+            t.w[n] = w_keras[j]; t.out[n] = reinterpret_cast<__bf16 *>(packed[j]); t.cin[n] = cin[j]; t.cout[n] = cout[j];
+            const int blocks = kind == 0 ? 64 * (cin[j] / 64) * (cout[j] / 64) : sd_grid_1d((long)8 * cin[j] * cout[j]);
+            t.first[n + 1] = t.first[n] + blocks;
+            t.njobs = n + 1;
+            if (t.njobs == SD_MAXJOBS) flush();
+        }
+        flush();
+        if (rc_all != VV_OK) return rc_all;
+    }
+    return VV_OK;
 }
 
 VV_EXPORT int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,

@@ -62,6 +62,7 @@ SIGNATURES = {
     'vv_conv3d_k4s2_skip_supported': (_i, [_i, _i, _i, _i]),
     'vv_convT3d_k4s2_skip_supported': (_i, [_i, _i, _i, _i]),
     'vv_pack_conv_k4_skip': (_i, [_vp, _vp, _i, _i, _vp]),
+    'vv_pack_skip_images': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'vv_pack_convT_k4s2_skip': (_i, [_vp, _vp, _i, _i, _vp]),
     'vv_conv3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'vv_convT3d_k4s2_skip_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -393,8 +393,10 @@ class Trainer:
         if not os.environ.get('VV_NO_SKIP') and (lib.vv_conv3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_conv3d_k4s2_pos_supported(side, cin, cout, dt)):
             # 8^3 -> 4^3 / 4^3 -> 2^3 (bf16): the whole-samples-in-LDS and position-major kernels of the evaluation path, raw output
             # (no scale / shift / activation: BatchNorm follows with batch statistics); their weight image is packed per use
-            wsk = self._aempty(64 * cin * cout)
-            L.call('vv_pack_conv_k4_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
+            wsk = getattr(self, '_prepacked', {}).get((0, w_keras.data_ptr(), cin, cout))
+            if wsk is None:
+                wsk = self._aempty(64 * cin * cout)
+                L.call('vv_pack_conv_k4_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
             if side == 4:
                 ws = self.ws.get(lib.vv_conv3d_k4s2_pos_workspace_bytes(B, cin, cout))
                 L.call('vv_conv3d_k4s2_pos_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
@@ -418,8 +420,10 @@ class Trainer:
         y = self._aempty(B, 2 * side, 2 * side, 2 * side, cout)
         lib = L.load()
         if not os.environ.get('VV_NO_SKIP') and (lib.vv_convT3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_convT3d_k4s2_pos_supported(side, cin, cout, dt)):
-            wsk = self._aempty(64 * cin * cout)              # 4^3 -> 8^3 / 2^3 -> 4^3 (bf16): see _conv
-            L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
+            wsk = getattr(self, '_prepacked', {}).get((1, w_keras.data_ptr(), cin, cout))     # 4^3 -> 8^3 / 2^3 -> 4^3 (bf16): see _conv
+            if wsk is None:
+                wsk = self._aempty(64 * cin * cout)
+                L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wsk), cin, cout, st)
             if side == 2:
                 ws = self.ws.get(lib.vv_convT3d_k4s2_pos_workspace_bytes(B, cin, cout))
                 L.call('vv_convT3d_k4s2_pos_fwd', L.ptr(x), L.ptr(wsk), None, None, L.ptr(y), B, side, cin, cout, 0, dt, L.ptr(ws), ws.numel(), st)
@@ -430,7 +434,9 @@ class Trainer:
                 and not os.environ.get('VV_NO_WHOLE')):
             # 8^3 x 128 -> 16^3 x 64 (the widest decoder layer forward, and the data gradient of the widest encoder layer):
             # whole-sample kernel; its weight image is packed here (the weights change every step)
-            wk = packed_whole                        # the forward layer: the engine's image; a data gradient packs its own
+            wk = packed_whole                        # the forward layer: the engine's image; a data gradient: the step's prepacked one
+            if wk is None:
+                wk = getattr(self, '_prepacked', {}).get((1, w_keras.data_ptr(), cin, cout))
             if wk is None:
                 wk = self._aempty(64 * cin * cout)
                 L.call('vv_pack_convT_k4s2_skip', L.ptr(w_keras), L.ptr(wk), cin, cout, st)
@@ -457,6 +463,7 @@ class Trainer:
         self.dec.ensure_packed(fold=False)      # (packing the decoder on a side stream under the encoder's forward was measured: +0.11 ms per step)
         self.grads.begin_step()
         self._set_producer_streams()
+        self._prepack()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)      # loss scaled by the GLOBAL batch (AE3D.py:46-48)
         enc_out, est = self._encoder_forward(x, B)
@@ -464,6 +471,55 @@ class Trainer:
         self._encoder_backward(x, de, est, B)
         self._apply()
         return kl, stats, metrics
+
+    def _prepack(self):
+        """Every skip / position / whole-sample weight image the step will ask for (forward layers and data gradients: nine at the 32^3
+        model), packed by ONE vv_pack_skip_images call = two launches, instead of nine 5-8 us launches spread over the step.  _conv /
+        _convT look the images up by (kind, weight pointer, cin, cout) and pack per use when they find none (other entry points).  The
+        images are dropped again when Adam has moved the weights (_apply)."""
+        self._prepacked = {}
+        if self.dt != L.VV_BF16 or os.environ.get('VV_NO_SKIP') or os.environ.get('VV_NO_PREPACK'):
+            return
+        lib, dt = L.load(), self.dt
+        jobs = []                                                     # (kind, weight tensor, cin, cout)
+
+        def conv_ok(side, cin, cout):
+            return side >= 2 and (lib.vv_conv3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_conv3d_k4s2_pos_supported(side, cin, cout, dt))
+
+        def convT_ok(side, cin, cout, whole):
+            if side >= 1 and (lib.vv_convT3d_k4s2_skip_supported(side, cin, cout, dt) or lib.vv_convT3d_k4s2_pos_supported(side, cin, cout, dt)):
+                return True
+            return bool(whole and lib.vv_convT3d_k4s2_whole_supported(side, cin, cout, dt) and not os.environ.get('VV_NO_DIRECT') and not os.environ.get('VV_NO_WHOLE'))
+
+        if self.enc is not None:
+            fe, side = self.enc.filters, self.enc.D // 2
+            for i in range(1, len(fe) - 1):
+                w = self.enc.params['conv%d/kernel' % i]
+                if conv_ok(side, fe[i - 1], fe[i]):
+                    jobs.append((0, w, fe[i - 1], fe[i]))             # the forward layer
+                if convT_ok(side // 2, fe[i], fe[i - 1], True):
+                    jobs.append((1, w, fe[i], fe[i - 1]))             # its data gradient (a transposed convolution with the same array)
+                side //= 2
+        fd, side = self.dec.filters, self.dec.S
+        for i in range(1, len(fd) - 1):
+            w = self.dec.params['convT%d/kernel' % i]
+            if convT_ok(side, fd[i - 1], fd[i], False):
+                jobs.append((1, w, fd[i - 1], fd[i]))                 # the forward layer (the whole-sample layer uses the engine's image)
+            if conv_ok(2 * side, fd[i], fd[i - 1]):
+                jobs.append((0, w, fd[i], fd[i - 1]))                 # its data gradient
+            side *= 2
+        if not jobs:
+            return
+        n = len(jobs)
+        outs = [self._aempty(64 * cin * cout) for _, _, cin, cout in jobs]
+        kinds = (ctypes.c_int * n)(*[k for k, _, _, _ in jobs])
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for _, w, _, _ in jobs])
+        op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        ci = (ctypes.c_int * n)(*[c for _, _, c, _ in jobs])
+        co = (ctypes.c_int * n)(*[c for _, _, _, c in jobs])
+        L.call('vv_pack_skip_images', kinds, wp, op, ci, co, n, _st())
+        for (k, w, cin, cout), o in zip(jobs, outs):
+            self._prepacked[(k, w.data_ptr(), cin, cout)] = o
 
     def _join_wgrad(self):
         """The launch stream waits for the weight-gradient stream: every weight gradient is in its bucket."""
@@ -483,6 +539,7 @@ class Trainer:
         self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
         self._set_producer_streams()
+        self._prepack()
         overlap, self.overlap = self.overlap, self.overlap and l2 == 0      # the l2 terms are added before the cross-rank sum
         B = enc_out.shape[0]
         inv_gb = 1.0 / float(B * self.world)
@@ -508,6 +565,7 @@ class Trainer:
         self.dec.ensure_packed(fold=False)
         self.grads.begin_step()
         self._set_producer_streams()
+        self._prepack()
         B = x.shape[0]
         inv_gb = 1.0 / float(B * self.world)
         enc_out, est = self._encoder_forward(x, B)
@@ -720,6 +778,7 @@ class Trainer:
     def _apply(self):
         # ---------------- cross-rank gradient sum, then Adam on every replica
         st = _st()
+        self._prepacked = {}                       # Adam moves the weights below: the step's images die with it
         self._join_wgrad()
         self.grads.finish(self.group)
         self.t += 1

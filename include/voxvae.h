@@ -155,6 +155,11 @@ int vv_convT3d_k4s2_direct_fp8_fwd(const void *x, const void *w_frag, const floa
 int vv_conv3d_k4s2_skip_supported(int side, int cin, int cout, int dtype);
 int vv_convT3d_k4s2_skip_supported(int side, int cin, int cout, int dtype);
 int vv_pack_conv_k4_skip(const float *w_keras, void *packed, int cin, int cout, void *stream);
+/* Several of the two images above in one call (round 4: the training step needs nine per step and each single call is a 5-8 us launch):
+ * kinds[j] = 0: vv_pack_conv_k4_skip, 1: vv_pack_convT_k4s2_skip of (w_keras[j], cin[j], cout[j]) into packed[j]; one launch per kind (and per
+ * eight jobs); bit-identical to the single calls.  The arrays are HOST arrays of njobs entries. */
+int vv_pack_skip_images(const int *kinds, const float *const *w_keras, void *const *packed, const int *cin, const int *cout, int njobs,
+                        void *stream);
 int vv_pack_convT_k4s2_skip(const float *w_keras, void *packed, int cin, int cout, void *stream);
 int vv_conv3d_k4s2_skip_fwd(const void *x, const void *w_skip, const float *scale, const float *shift, void *y, int batch,
                             int side, int cin, int cout, int act, int dtype, void *stream);

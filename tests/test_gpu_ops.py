@@ -216,6 +216,38 @@ def test_convT3d_whole_stats_form(L, B):
     assert lib.vv_convT3d_k4s2_whole_stats_fwd(L.ptr(x), L.ptr(wk), L.ptr(y1), L.ptr(part), 16, B, 8, cin, cout, L.VV_BF16, _st()) == -5
 
 
+def test_pack_skip_images_batched_equals_single_calls(L):
+    """vv_pack_skip_images (round 4: the training step's nine skip / position / whole-sample weight images in two launches) writes the
+    bits of the single vv_pack_conv_k4_skip / vv_pack_convT_k4s2_skip calls -- mixed kinds, more than eight jobs of one kind, bad
+    arguments refused."""
+    import ctypes
+    g = torch.Generator(device=DEV).manual_seed(9)
+    shapes = [(0, 128, 256), (1, 512, 256), (0, 256, 512), (1, 256, 128), (1, 128, 64), (0, 64, 64), (1, 64, 128), (0, 128, 64), (1, 64, 64),
+              (1, 128, 128), (1, 192, 64), (1, 64, 192), (1, 256, 64), (1, 64, 256)]          # 10 of kind 1: two launches of that kind
+    ws = [torch.randn(4, 4, 4, (cin if k == 0 else cout), (cout if k == 0 else cin), device=DEV, generator=g).contiguous() for k, cin, cout in shapes]
+    ref = []
+    for (k, cin, cout), w in zip(shapes, ws):
+        o = torch.full((64 * cin * cout,), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.call('vv_pack_conv_k4_skip' if k == 0 else 'vv_pack_convT_k4s2_skip', L.ptr(w), L.ptr(o), cin, cout, _st())
+        ref.append(o)
+    outs = [torch.full_like(r, float('nan')) for r in ref]
+    n = len(shapes)
+    kinds = (ctypes.c_int * n)(*[k for k, _, _ in shapes])
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    ci = (ctypes.c_int * n)(*[c for _, c, _ in shapes])
+    co = (ctypes.c_int * n)(*[c for _, _, c in shapes])
+    L.call('vv_pack_skip_images', kinds, wp, op, ci, co, n, _st())
+    torch.cuda.synchronize()
+    for (k, cin, cout), a, b in zip(shapes, ref, outs):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (k, cin, cout)
+    lib = L.load()
+    bad = (ctypes.c_int * 1)(2)
+    assert lib.vv_pack_skip_images(bad, wp, op, ci, co, 1, _st()) == -2
+    assert lib.vv_pack_skip_images(kinds, wp, op, ci, co, 0, _st()) == -2
+    assert lib.vv_pack_skip_images(None, wp, op, ci, co, 1, _st()) == -1
+
+
 # position-major split-K GEMM of the 4^3 <-> 2^3 layers (posgemm.hip): ragged batches, channel tails, several sample tiles
 @pytest.mark.parametrize('act', [1, 0])
 @pytest.mark.parametrize('B,cin,cout', [(5, 64, 64), (37, 256, 512), (256, 128, 136), (300, 64, 128)])
